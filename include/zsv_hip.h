@@ -1,0 +1,143 @@
+/*
+ * zsv_hip.h -- C ABI of libzsv_hip.so: the MI355X (gfx950) kernels behind the
+ * 3D-conv video hot path of damien911224/ZeroShotVideoClassification.
+ *
+ * The reference has no native code and no FFI of its own: every entry point below
+ * replaces an ATen operator that the reference's Python reaches through torch.nn
+ * (SURVEY.md section 2a / 8b).  Each declaration cites the reference call site whose
+ * arithmetic it supplies.  Conventions:
+ *
+ *   - all tensors are contiguous fp32, channel-major "NCS": (N, C, T, H, W) with
+ *     S = T*H*W; pointers are device pointers owned by the caller;
+ *   - kernels never allocate: workspaces are passed in (query the size first);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - return value: 0 = OK, otherwise a ZSV_E_* code (zsv_status_string() names it);
+ *     nothing throws across this boundary;
+ *   - re-entrant and thread-safe (backward is called from autograd's worker thread).
+ */
+#ifndef ZSV_HIP_H
+#define ZSV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZSV_OK 0
+#define ZSV_E_BAD_SHAPE 1      /* inconsistent or unsupported geometry            */
+#define ZSV_E_NULL 2           /* required pointer is NULL                        */
+#define ZSV_E_WORKSPACE 3      /* workspace smaller than the *_workspace_bytes()  */
+#define ZSV_E_TOO_LARGE 4      /* a tensor has >= 2^31 elements                   */
+#define ZSV_E_LAUNCH 5         /* hipGetLastError() after the launch was not OK   */
+#define ZSV_E_UNSUPPORTED 6    /* valid but not implemented (e.g. overlapping pool) */
+
+/* Geometry of one Conv3d call site.  Replaces the arguments of
+ * nn.Conv3d / F.conv3d at resnet.py:40-52 (Conv2Plus1D spatial 1xkxk and temporal
+ * tx1x1), resnet.py:23-30 (3x3x3), resnet.py:63-70 (1x3x3), resnet.py:170,181,184
+ * (stems), resnet.py:270 (1x1x1 strided shortcut) and network.py:102-117 (C3D).
+ * Dilation is 1 and groups is 1 everywhere in the reference. */
+typedef struct zsv_conv_desc {
+    int32_t N, Cin, Ti, Hi, Wi;    /* input  (N, Cin, Ti, Hi, Wi)                 */
+    int32_t Cout, To, Ho, Wo;      /* output (N, Cout, To, Ho, Wo)                */
+    int32_t kT, kH, kW;            /* weight (Cout, Cin, kT, kH, kW)              */
+    int32_t sT, sH, sW;            /* stride                                      */
+    int32_t pT, pH, pW;            /* zero padding                                */
+} zsv_conv_desc;
+
+const char* zsv_status_string(int status);
+/* build identification: "zsv_hip gfx950 <date>" */
+const char* zsv_version(void);
+
+/* ---- convolution (aten::conv3d and its autograd formulas) ------------------- */
+/* y = conv3d(x, w) (+ bias[c]) (relu optional, for network.py:147-162 `relu(conv(x))`). */
+int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                   float* y, int fuse_relu, void* stream);
+/* dx = conv3d_input_grad(dy, w): what autograd runs for every conv but the first. */
+int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
+                     void* stream);
+/* dw = conv3d_weight_grad(x, dy).  Deterministic: position range is cut into a fixed
+ * number of slices, each slice writes a partial slab into `workspace`, a second kernel
+ * sums the slabs in slice order. */
+size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d);
+int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* db[c] = sum over (n, s) of dy  (bias gradient of C3D's convs, network.py:102-117,
+ * and of nn.Linear when S == 1). */
+size_t zsv_channel_sum_workspace_bytes(int32_t N, int32_t C, int32_t S);
+int zsv_channel_sum(const float* dy, int32_t N, int32_t C, int32_t S, float* db,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm3d (+ fused residual add / ReLU) ------------------------------- */
+/* Training-mode forward of nn.BatchNorm3d (resnet.py:48,95,97,183,186,272) followed,
+ * optionally, by `out += residual` (resnet.py:110) and ReLU (resnet.py:49,95,111):
+ *   mean/var over (N, S) per channel (biased var for normalising),
+ *   running_mean/var updated in place with `momentum` (unbiased var), like torch;
+ *   y = relu?((x - mean) * invstd * gamma + beta + residual?)
+ * save_mean / save_invstd (C floats each) are kept for backward. */
+size_t zsv_bn_workspace_bytes(int32_t N, int32_t C, int32_t S);
+int zsv_bn_fwd_train(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
+                     const float* beta, const float* residual, int fuse_relu, float* y,
+                     float* save_mean, float* save_invstd, float* running_mean,
+                     float* running_var, float momentum, float eps, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* Eval-mode forward (model.eval(), main.py:229): uses the running statistics. */
+int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
+                    const float* beta, const float* running_mean, const float* running_var,
+                    const float* residual, int fuse_relu, float eps, float* y, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* Backward of the fused op.  `y` is the saved OUTPUT (needed only when fuse_relu, as the
+ * ReLU mask, cf. nn.ReLU(inplace=True) which also keeps only its output).  Writes
+ * dx, dgamma, dbeta and, when d_residual != NULL, the gradient flowing into the
+ * residual branch (= dy masked by the ReLU). */
+int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+               const float* gamma, const float* save_mean, const float* save_invstd,
+               int fuse_relu, float* dx, float* d_residual, float* dgamma, float* dbeta,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- elementwise -------------------------------------------------------------- */
+/* nn.ReLU / F.relu (resnet.py:49; network.py:147-166,614). */
+int zsv_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+/* dx = dy * (y > 0), y = saved output. */
+int zsv_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* out = relu(a + b): `out += residual; relu(out)` (resnet.py:110-111) when no BN is fused. */
+int zsv_add_relu_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+/* ---- pooling -------------------------------------------------------------------- */
+/* torch.mean(f, dim=(2,3,4)) (network.py:595) / AdaptiveAvgPool3d(1) (resnet.py:251). */
+int zsv_meanpool_fwd(const float* x, int32_t N, int32_t C, int32_t S, float* y, void* stream);
+int zsv_meanpool_bwd(const float* dy, int32_t N, int32_t C, int32_t S, float* dx, void* stream);
+/* nn.MaxPool3d with kernel == stride (network.py:103-118); padding is -inf padding.
+ * `argmax` (int32, one per output element) holds the flat (t*H+h)*W+w input index. */
+int zsv_maxpool3d_fwd(const float* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi,
+                      int32_t kT, int32_t kH, int32_t kW, int32_t pT, int32_t pH, int32_t pW,
+                      int32_t To, int32_t Ho, int32_t Wo, float* y, int32_t* argmax, void* stream);
+int zsv_maxpool3d_bwd(const float* dy, const int32_t* argmax, int32_t N, int32_t C, int32_t Ti,
+                      int32_t Hi, int32_t Wi, int32_t kT, int32_t kH, int32_t kW, int32_t pT,
+                      int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo, float* dx,
+                      void* stream);
+
+/* ---- dense head ----------------------------------------------------------------- */
+/* nn.Linear (network.py:611-616 MLP, :120,132 fc6/regressor): y = x W^T + b, optional ReLU.
+ * x (rows, in), w (out, in), y (rows, out).  Implemented on the same MFMA GEMM core. */
+int zsv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t rows,
+                   int32_t in_features, int32_t out_features, int fuse_relu, void* stream);
+int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int32_t rows,
+                     int32_t in_features, int32_t out_features, void* stream);
+size_t zsv_linear_wgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features);
+int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
+                     int32_t in_features, int32_t out_features, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------------ */
+/* One torch.optim.Adam step (main.py:131; betas (0.9, 0.999), eps 1e-8, no weight decay,
+ * no amsgrad) over a flat fp32 buffer: p, g, exp_avg, exp_avg_sq of n elements.
+ * `step` is the 1-based step count (bias correction). */
+int zsv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZSV_HIP_H */

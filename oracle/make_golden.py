@@ -1,0 +1,203 @@
+"""Generate ``tests/golden/*.npz`` from the REFERENCE's own modules -- TEST INFRASTRUCTURE.
+
+Run in the build container only (needs ``/root/reference``):
+
+    python -m oracle.make_golden
+
+For each case the reference model (``network.get_network`` imported through
+``oracle/reference_import.py``) is given the name-keyed synthetic weights and the
+synthetic clips of ``zeroshotvideoclassification_amd.synthetic``; inputs are
+regenerated from seeds on the consuming side, so only the expected outputs are stored.
+Every case also checks that ``oracle/restatement.py`` reproduces the reference
+bit-for-bit on the same inputs (the restatement is what travels to the GPU box).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import restatement as R                                   # noqa: E402
+from oracle.reference_import import import_reference                    # noqa: E402
+from zeroshotvideoclassification_amd import synthetic as S             # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name, network, N, T, HW, bn_jitter, train?
+CASES = [
+    dict(name="r2plus1d_A", network="r2plus1d_18", n=2, frames=16, size=112, bn_jitter=False),
+    dict(name="r2plus1d_jitter", network="r2plus1d_18", n=2, frames=16, size=112, bn_jitter=True),
+    dict(name="r2plus1d_small", network="r2plus1d_18", n=3, frames=8, size=56, bn_jitter=True),
+    dict(name="r3d_small", network="r3d_18", n=2, frames=8, size=56, bn_jitter=True),
+    dict(name="c3d_eval", network="c3d", n=1, frames=16, size=112, bn_jitter=False),
+]
+
+
+def sample_idx(numel: int, k: int = 64) -> np.ndarray:
+    return np.unique(np.linspace(0, numel - 1, num=min(k, numel)).astype(np.int64))
+
+
+def bn_inputs_stats(model):
+    """Hook every BatchNorm3d: batch mean / biased var of its input, in call order."""
+    stats, hooks = OrderedDict(), []
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            def hook(mod, inp, _out, name=name):
+                x = inp[0].detach().double()
+                stats[name] = (x.mean(dim=(0, 2, 3, 4)).float().numpy(),
+                               x.var(dim=(0, 2, 3, 4), unbiased=False).float().numpy())
+            hooks.append(m.register_forward_hook(hook))
+    return stats, hooks
+
+
+def run_case(case, ref_network):
+    opt = R.make_opt(case["network"])
+    torch.manual_seed(0)
+    ref = ref_network.get_network(opt)
+    mine = R.oracle_network(opt)
+    sd_ref = ref.state_dict()
+    sd_mine = mine.state_dict()
+    assert list(sd_ref.keys()) == list(sd_mine.keys()), "state_dict keys/order differ from the reference"
+    for k in sd_ref:
+        assert sd_ref[k].shape == sd_mine[k].shape, k
+    weights = S.keyed_state_dict(sd_ref, seed=0, bn_jitter=case["bn_jitter"])
+    ref.load_state_dict(weights)
+    mine.load_state_dict(weights)
+
+    n = case["n"]
+    x = S.synthetic_clips(n, case["frames"], case["size"])
+    _, z = S.synthetic_targets(n)
+    out = {}
+    is_c3d = case["network"] == "c3d"
+    if is_c3d:          # dropout makes train mode RNG dependent: eval parity
+        ref.eval(); mine.eval()
+    else:
+        ref.train(); mine.train()
+
+    # ---- fp32 forward + backward on the reference; restatement must match bit for bit
+    stats, hooks = ({}, [])
+    if not is_c3d:
+        stats, hooks = bn_inputs_stats(ref)
+    y_ref = R.embed(ref, x)
+    loss_ref = F.mse_loss(y_ref, z)
+    loss_ref.backward()
+    for h in hooks:
+        h.remove()
+    y_mine = R.embed(mine, x)
+    loss_mine = F.mse_loss(y_mine, z)
+    loss_mine.backward()
+    assert torch.equal(y_ref, y_mine), "restatement forward differs from the reference"
+    assert torch.equal(loss_ref, loss_mine)
+    g_ref = {k: p.grad for k, p in ref.named_parameters()}
+    g_mine = {k: p.grad for k, p in mine.named_parameters()}
+    for k in g_ref:
+        assert (g_ref[k] is None) == (g_mine[k] is None), k
+        if g_ref[k] is not None:
+            assert torch.equal(g_ref[k], g_mine[k]), f"restatement grad differs: {k}"
+    out["emb_f32"] = y_ref.detach().numpy()
+    out["loss_f32"] = np.float64(loss_ref.item())
+    out["live_params"] = np.array([k for k, g in g_ref.items() if g is not None])
+    out["dead_params"] = np.array([k for k, g in g_ref.items() if g is None])
+    if stats:
+        out["bn_names"] = np.array(list(stats.keys()))
+        out["bn_mean"] = np.concatenate([v[0] for v in stats.values()])
+        out["bn_var"] = np.concatenate([v[1] for v in stats.values()])
+
+    # stage statistics (trunk models only)
+    if not is_c3d:
+        with torch.no_grad():
+            trunk = ref.model
+            t = x.reshape(n, *x.shape[2:])
+            feats = [trunk.stem(t)]
+            for i in range(1, 5):
+                feats.append(getattr(trunk, f"layer{i}")(feats[-1]))
+        for name, f in zip(["stem", "layer1", "layer2", "layer3", "layer4"], feats):
+            flat = f.flatten()
+            out[f"stage_{name}_mean"] = np.float64(flat.double().mean().item())
+            out[f"stage_{name}_absmean"] = np.float64(flat.double().abs().mean().item())
+            out[f"stage_{name}_sample"] = flat[sample_idx(flat.numel())].numpy()
+        # NOTE: the no_grad forward above ran BN in train mode once more -> running stats were
+        # updated twice so far on ``ref``; the step below re-loads weights to keep this clean.
+
+    # ---- fp64 reference: embeddings, loss, per-parameter gradient norms + samples
+    ref64 = ref_network.get_network(opt).double()
+    ref64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in weights.items()})
+    ref64.eval() if is_c3d else ref64.train()
+    y64 = R.embed(ref64, x.double())
+    loss64 = F.mse_loss(y64, z.double())
+    loss64.backward()
+    out["emb_f64"] = y64.detach().numpy()
+    out["loss_f64"] = np.float64(loss64.item())
+    names, norms, samples = [], [], []
+    for k, p in ref64.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.flatten()
+        names.append(k)
+        norms.append(g.norm().item())
+        s = np.zeros(16)
+        idx = sample_idx(g.numel(), 16)
+        s[:len(idx)] = g[idx].numpy()
+        samples.append(s)
+    out["grad_names"] = np.array(names)
+    out["grad_norm_f64"] = np.array(norms)
+    out["grad_sample_f64"] = np.stack(samples)
+
+    # ---- one full Adam step in fp32 from fresh weights, then eval-mode embeddings
+    if not is_c3d:
+        ref.load_state_dict(weights)
+        ref.train()
+        opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3)
+        y1, l1 = R.train_step(ref, opt_ref, x, z)
+        sd_after = ref.state_dict()
+        rm = [sd_after[k].numpy() for k in sd_after if k.endswith("running_mean")]
+        rv = [sd_after[k].numpy() for k in sd_after if k.endswith("running_var")]
+        out["running_mean_after1"] = np.concatenate(rm)
+        out["running_var_after1"] = np.concatenate(rv)
+        out["step1_loss"] = np.float64(l1.item())
+        y2, l2 = R.train_step(ref, opt_ref, x, z)
+        out["step2_loss"] = np.float64(l2.item())
+        # eval-mode embeddings from the *initial* weights (deterministic, no Adam sign noise)
+        ref.load_state_dict(weights)
+        ref.eval()
+        with torch.no_grad():
+            out["emb_eval_f32"] = R.embed(ref, x).numpy()
+            if case["name"] == "r2plus1d_jitter":      # config E shape: 32-frame clips, eval BN
+                x32 = S.synthetic_clips(1, 32, case["size"], seed=99)
+                out["emb_eval_t32_f32"] = R.embed(ref, x32).numpy()
+    else:
+        ref.eval()
+        with torch.no_grad():
+            out["emb_eval_f32"] = R.embed(ref, x).numpy()
+    return out
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref_network, _ = import_reference()
+    os.makedirs(GOLDEN, exist_ok=True)
+    only = set(sys.argv[1:])
+    for case in CASES:
+        if only and case["name"] not in only:
+            continue
+        t0 = time.time()
+        out = run_case(case, ref_network)
+        meta = {"meta_" + k: np.array(v) for k, v in case.items()}
+        meta["meta_torch"] = np.array(torch.__version__)
+        path = os.path.join(GOLDEN, case["name"] + ".npz")
+        np.savez_compressed(path, **out, **meta)
+        print(f"{case['name']}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.1f}s "
+              f"loss32={out['loss_f32']:.8f} loss64={out['loss_f64']:.8f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against torch CPU fp64.
+
+Tolerances: fp32 accumulation over K terms against an fp64 reference; the bound used is
+max|err| <= 2e-5 * max|ref| (+ tiny abs), far inside the 1e-3 bar north_star states.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from zeroshotvideoclassification_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def close(a, ref, rtol=2e-5, what=""):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(ref.shape)}"
+    scale = ref.abs().max().item() + 1e-30
+    err = (a - ref).abs().max().item()
+    assert err <= rtol * scale + 1e-12, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+
+
+CONV_CASES = [
+    # name, N, Cin, T, H, W, Cout, k, s, p, bias
+    ("spatial_s1", 2, 8, 3, 10, 12, 20, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("spatial_s2", 2, 16, 2, 14, 14, 45, (1, 3, 3), (1, 2, 2), (0, 1, 1), False),
+    ("spatial_144", 1, 64, 2, 12, 12, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1), False),
+    ("stem_7x7", 2, 3, 2, 30, 30, 45, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),
+    ("temporal_s1", 2, 45, 6, 7, 9, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), False),
+    ("temporal_s2", 2, 30, 8, 6, 6, 17, (3, 1, 1), (2, 1, 1), (1, 0, 0), False),
+    ("pointwise_s2", 2, 24, 4, 8, 8, 40, (1, 1, 1), (2, 2, 2), (0, 0, 0), False),
+    ("full_333", 2, 5, 4, 9, 9, 12, (3, 3, 3), (1, 1, 1), (1, 1, 1), True),
+    ("full_333_s2", 1, 12, 6, 11, 11, 20, (3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+    ("stem_3x7x7", 1, 3, 4, 20, 20, 64, (3, 7, 7), (1, 2, 2), (1, 3, 3), False),
+    ("wide_230", 1, 64, 2, 8, 8, 230, (1, 3, 3), (1, 2, 2), (0, 1, 1), False),
+    ("deep_k", 3, 288, 2, 7, 7, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), False),
+    ("one_voxel", 1, 7, 1, 1, 1, 5, (1, 1, 1), (1, 1, 1), (0, 0, 0), True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3d_fwd_dgrad_wgrad(case):
+    name, n, cin, t, h, w, cout, k, s, p, has_bias = case
+    g = torch.Generator().manual_seed(hash(name) % 2**31)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+    b = torch.randn(cout, generator=g) if has_bias else None
+    xr = x.double().requires_grad_()
+    wr = wt.double().requires_grad_()
+    br = b.double().requires_grad_() if has_bias else None
+    yr = F.conv3d(xr, wr, br, stride=s, padding=p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xg = x.to(DEV).requires_grad_()
+    wg = wt.to(DEV).requires_grad_()
+    bg = b.to(DEV).requires_grad_() if has_bias else None
+    yg = ops.conv3d(xg, wg, bg, s, p)
+    close(yg, yr, what=f"{name} fwd")
+    yg.backward(dy.to(DEV))
+    close(xg.grad, xr.grad, what=f"{name} dgrad")
+    close(wg.grad, wr.grad, what=f"{name} wgrad")
+    if has_bias:
+        close(bg.grad, br.grad, what=f"{name} dbias")
+
+
+def test_conv3d_relu_fused_and_determinism():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 6, 4, 9, 9, generator=g)
+    wt = torch.randn(10, 6, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(10, generator=g)
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.relu(F.conv3d(xr, wr, br, padding=1))
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    outs = []
+    for _ in range(2):
+        xg, wg, bg = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        yg = ops.conv3d(xg, wg, bg, 1, 1, relu=True)
+        yg.backward(dy.to(DEV))
+        outs.append((yg.detach().clone(), xg.grad.clone(), wg.grad.clone(), bg.grad.clone()))
+    close(outs[0][0], yr, what="conv+relu fwd")
+    close(outs[0][1], xr.grad, what="conv+relu dgrad")
+    close(outs[0][2], wr.grad, what="conv+relu wgrad")
+    close(outs[0][3], br.grad, what="conv+relu dbias")
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_), "kernels must be bitwise reproducible run to run"
+
+
+def test_conv3d_wgrad_many_slices():
+    # long voxel axis -> several slabs in the deterministic split reduction
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 8, 8, 28, 28, generator=g)
+    wt = torch.randn(16, 8, 1, 3, 3, generator=g) * 0.1
+    xr, wr = x.double(), wt.double().requires_grad_()
+    yr = F.conv3d(xr, wr, padding=(0, 1, 1))
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg = x.to(DEV), wt.to(DEV).requires_grad_()
+    ops.conv3d(xg, wg, None, 1, (0, 1, 1)).backward(dy.to(DEV))
+    close(wg.grad, wr.grad, rtol=5e-5, what="wgrad slabs")
+
+
+def test_conv3d_rejects_bad_inputs():
+    x = torch.randn(1, 3, 2, 4, 4)
+    w = torch.randn(4, 3, 1, 3, 3)
+    with pytest.raises(RuntimeError):
+        ops.conv3d(x, w)                      # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        ops.conv3d(x.to(DEV), torch.randn(4, 5, 1, 3, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.conv3d(x.to(DEV).half(), w.to(DEV).half())
+
+
+BN_CASES = [(2, 5, (3, 4, 4)), (3, 45, (2, 7, 7)), (2, 64, (4, 8, 8)), (4, 7, (1, 1, 1)), (2, 130, (2, 7, 7))]
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("use_res", [False, True])
+@pytest.mark.parametrize("shape", BN_CASES, ids=[f"{n}x{c}x{'x'.join(map(str, s))}" for n, c, s in BN_CASES])
+def test_batchnorm_train_fwd_bwd(shape, use_res, relu):
+    n, c, sp = shape
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    x = torch.randn(n, c, *sp, generator=g) * 2 + 0.5
+    res = torch.randn(n, c, *sp, generator=g) if use_res else None
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.1
+    rm0 = torch.randn(c, generator=g) * 0.1
+    rv0 = torch.rand(c, generator=g) + 0.5
+    dy = torch.randn(n, c, *sp, generator=g)
+
+    xr = x.double().requires_grad_()
+    gr, br = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rr = res.double().requires_grad_() if use_res else None
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    yr = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if use_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.double())
+
+    xg = x.to(DEV).requires_grad_()
+    gg, bg = gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    rg = res.to(DEV).requires_grad_() if use_res else None
+    rmg, rvg = rm0.to(DEV), rv0.to(DEV)
+    yg = ops.batch_norm_act(xg, gg, bg, rmg, rvg, rg, True, 0.1, 1e-5, relu)
+    close(yg, yr, what="bn fwd")
+    close(rmg, rm, what="running_mean")
+    close(rvg, rv, what="running_var")
+    yg.backward(dy.to(DEV))
+    close(xg.grad, xr.grad, rtol=1e-4, what="bn dx")
+    close(gg.grad, gr.grad, rtol=1e-4, what="bn dgamma")
+    close(bg.grad, br.grad, rtol=1e-4, what="bn dbeta")
+    if use_res:
+        close(rg.grad, rr.grad, what="bn dres")
+
+
+def test_batchnorm_eval():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 9, 2, 5, 5, generator=g)
+    gamma, beta = torch.rand(9, generator=g) + 0.5, torch.randn(9, generator=g)
+    rm, rv = torch.randn(9, generator=g), torch.rand(9, generator=g) + 0.5
+    ref = F.relu(F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), training=False))
+    out = ops.batch_norm_act(x.to(DEV), gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), None, False, 0.1, 1e-5, True)
+    close(out, ref, what="bn eval")
+
+
+def test_batchnorm_large_mean_is_stable():
+    # |mean| >> std: the sum/sumsq formulation must still give an accurate variance
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 6, 4, 16, 16, generator=g) * 0.5 + 10.0
+    ref = F.batch_norm(x.double(), None, None, None, None, training=True)
+    out = ops.batch_norm_act(x.to(DEV), None, None, None, None, None, True, 0.1, 1e-5, False)
+    close(out, ref, rtol=2e-4, what="bn shifted")
+
+
+def test_relu_add_relu_meanpool():
+    g = torch.Generator().manual_seed(2)
+    for numel_shape in [(3, 5, 2, 7, 7), (1, 1, 1, 1, 3), (2, 4, 4, 8, 8)]:
+        a = torch.randn(*numel_shape, generator=g)
+        b = torch.randn(*numel_shape, generator=g)
+        dy = torch.randn(*numel_shape, generator=g)
+        ar, br = a.double().requires_grad_(), b.double().requires_grad_()
+        yr = F.relu(ar + br)
+        yr.backward(dy.double())
+        ag, bg = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        yg = ops.add_relu(ag, bg)
+        yg.backward(dy.to(DEV))
+        close(yg, yr, what="add_relu")
+        close(ag.grad, ar.grad, what="add_relu da")
+        close(bg.grad, br.grad, what="add_relu db")
+
+        ar2 = a.double().requires_grad_()
+        F.relu(ar2).backward(dy.double())
+        ag2 = a.to(DEV).requires_grad_()
+        y2 = ops.relu(ag2)
+        y2.backward(dy.to(DEV))
+        close(y2, F.relu(a.double()), what="relu")
+        close(ag2.grad, ar2.grad, what="relu bwd")
+
+        ar3 = a.double().requires_grad_()
+        mr = ar3.mean(dim=(2, 3, 4))
+        dm = torch.randn(mr.shape, generator=g)
+        mr.backward(dm.double())
+        ag3 = a.to(DEV).requires_grad_()
+        mg = ops.mean_pool(ag3)
+        mg.backward(dm.to(DEV))
+        close(mg, mr, what="meanpool")
+        close(ag3.grad, ar3.grad, what="meanpool bwd")
+
+
+POOL_CASES = [((1, 2, 2), (0, 0, 0), (2, 3, 4, 8, 8)), ((2, 2, 2), (0, 0, 0), (1, 5, 4, 6, 6)),
+              ((2, 2, 2), (0, 1, 1), (2, 4, 2, 7, 7)), ((2, 2, 2), (0, 0, 0), (1, 2, 5, 9, 7))]
+
+
+@pytest.mark.parametrize("k,p,shape", POOL_CASES)
+def test_maxpool3d(k, p, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = F.relu(torch.randn(*shape, generator=g))          # ties at 0 like post-ReLU activations
+    xr = x.double().requires_grad_()
+    yr = F.max_pool3d(xr, k, k, p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg = x.to(DEV).requires_grad_()
+    yg = ops.max_pool3d(xg, k, k, p)
+    yg.backward(dy.to(DEV))
+    close(yg, yr, what="maxpool")
+    close(xg.grad, xr.grad, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("rows,fin,fout,relu", [(22, 512, 512, True), (22, 512, 300, False), (3, 37, 11, False),
+                                                 (1, 8192, 64, True)])
+def test_linear(rows, fin, fout, relu):
+    g = torch.Generator().manual_seed(rows + fin)
+    x = torch.randn(rows, fin, generator=g)
+    w = torch.randn(fout, fin, generator=g) / np.sqrt(fin)
+    b = torch.randn(fout, generator=g)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = F.linear(xr, wr, br)
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg, bg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    yg = ops.linear(xg, wg, bg, relu=relu)
+    yg.backward(dy.to(DEV))
+    close(yg, yr, what="linear")
+    close(xg.grad, xr.grad, what="linear dx")
+    close(wg.grad, wr.grad, what="linear dw")
+    close(bg.grad, br.grad, what="linear db")
+
+
+def test_adam_step_matches_torch():
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(1000, generator=g)
+    pr = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pg = p0.to(DEV)
+    m = torch.zeros_like(pg)
+    v = torch.zeros_like(pg)
+    for step in range(1, 4):
+        grad = torch.randn(1000, generator=g)
+        pr.grad = grad.clone()
+        opt.step()
+        ops.adam_step_(pg, grad.to(DEV), m, v, step, 1e-3)
+    close(pg, pr, rtol=1e-6, what="adam")

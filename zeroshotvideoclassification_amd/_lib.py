@@ -1,0 +1,86 @@
+"""ctypes binding of ``libzsv_hip.so`` (C ABI declared in ``include/zsv_hip.h``).
+
+The shared object is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``) with
+plain ``hipcc --offload-arch=gfx950``; nothing in its signatures is a torch type -- Python
+passes ``tensor.data_ptr()`` and the current HIP stream handle.  There is NO fallback: if
+the library is missing, or an op is called on a non-HIP tensor, a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzsv_hip.so")
+
+
+class ConvDesc(Structure):
+    """Mirror of ``zsv_conv_desc`` (include/zsv_hip.h)."""
+    _fields_ = [(n, c_int32) for n in (
+        "N", "Cin", "Ti", "Hi", "Wi", "Cout", "To", "Ho", "Wo",
+        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW")]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every symbol include/zsv_hip.h declares
+SIGNATURES = {
+    "zsv_status_string": (c_char_p, [c_int]),
+    "zsv_version": (c_char_p, []),
+    "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P]),
+    "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
+    "zsv_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "zsv_conv3d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_channel_sum_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "zsv_channel_sum": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "zsv_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "zsv_bn_fwd_train": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
+                                 c_float, c_float, _P, c_size_t, _P]),
+    "zsv_bn_fwd_eval": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int, c_float, _P, _P,
+                                c_size_t, _P]),
+    "zsv_bn_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
+                           c_size_t, _P]),
+    "zsv_relu_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "zsv_relu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "zsv_add_relu_fwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "zsv_meanpool_fwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "zsv_meanpool_bwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "zsv_maxpool3d_fwd": (c_int, [_P] + [c_int32] * 14 + [_P, _P, _P]),
+    "zsv_maxpool3d_bwd": (c_int, [_P, _P] + [c_int32] * 14 + [_P, _P]),
+    "zsv_linear_fwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int, _P]),
+    "zsv_linear_dgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "zsv_linear_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "zsv_linear_wgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the library; raises ``RuntimeError`` when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.isfile(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: build the HIP extension first "
+                    "(python -c 'import __graft_entry__ as g; g.build()' or make -C "
+                    "zeroshotvideoclassification_amd/csrc). There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().zsv_status_string(int(status)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (zsv status {status})")

@@ -1,0 +1,383 @@
+// batchnorm.hip -- BatchNorm3d forward/backward (+ fused residual add and ReLU), gfx950.
+//
+// Supplies aten::native_batch_norm / native_batch_norm_backward for every
+// nn.BatchNorm3d of the reference (resnet.py:48,95,97,183,186,272), with the
+// `out += residual; relu(out)` of BasicBlock.forward (resnet.py:110-111) and the ReLU of
+// Conv2Plus1D / stems (resnet.py:49,95,184,187) fused into the same HBM pass.
+//
+// These are HBM-bound passes over (N, C, S) fp32 tensors (S = T*H*W contiguous):
+//   stats   : one read of x            -> per (channel, slice) partial (sum, sumsq)
+//   finalize: C threads                -> mean, invstd, scale/shift, running stats
+//   apply   : read x (+res), write y   -> float4 along S when S % 4 == 0
+//   bwd     : reduce (read dy, x, y) + apply (read dy, x, y; write dx (+dres))
+// Per-thread partial sums are fp32 over <= ~128 elements, combined in fp64 with
+// wave-level shuffles (64-wide) and a 4-entry LDS exchange; the slices of a channel are
+// summed in fixed order, so results are bitwise reproducible run to run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zsv_hip.h"
+#include "zsv_common.h"
+
+namespace zsv {
+
+// slices per channel so that every channel has enough workgroups in flight and a thread
+// accumulates a bounded number of fp32 terms
+static inline int bn_slices(int N, int C, int S) {
+    const long per_channel = (long)N * S;
+    long want = (2048 + C - 1) / C;                 // ~8 workgroups per CU overall
+    long by_len = (per_channel + 256L * 128 - 1) / (256L * 128);   // <= 128 terms per thread
+    long s = want > by_len ? want : by_len;
+    long max_s = (per_channel + 1023) / 1024;       // at least 1024 elements per slice
+    if (max_s < 1) max_s = 1;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+// workspace layout: double part[2][C][slices] | float scale[C] | float shift[C] | float c1[C] | float c2[C]
+struct BnWs {
+    double* part;
+    float* scale;
+    float* shift;
+    float* c1;
+    float* c2;
+};
+static inline size_t bn_ws_bytes(int N, int C, int S) {
+    const int sl = bn_slices(N, C, S);
+    return (size_t)2 * C * sl * sizeof(double) + (size_t)4 * C * sizeof(float);
+}
+static inline BnWs bn_ws(void* ws, int C, int slices) {
+    BnWs w;
+    w.part = (double*)ws;
+    w.scale = (float*)(w.part + (size_t)2 * C * slices);
+    w.shift = w.scale + C;
+    w.c1 = w.shift + C;
+    w.c2 = w.c1 + C;
+    return w;
+}
+
+// The (n, s) domain of one channel is N*S elements; slice `sl` owns the contiguous range
+// [sl*len, (sl+1)*len) of it, len a multiple of 4 when S % 4 == 0.
+__device__ __forceinline__ void slice_range(int total, int slices, int sl, bool vec, int& b, int& e) {
+    int len = (total + slices - 1) / slices;
+    if (vec) len = (len + 3) & ~3;
+    const long bl = (long)sl * len;
+    b = bl > total ? total : (int)bl;
+    e = (total - b < len) ? total : b + len;
+}
+
+// ---- forward statistics ------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int S, int slices,
+                                                       double* __restrict__ part) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const bool vec = (S % 4) == 0;
+    int b, e;
+    slice_range(N * S, slices, sl, vec, b, e);
+    float s1 = 0.f, s2 = 0.f;
+    if (vec) {
+        for (int i = b + 4 * (int)threadIdx.x; i < e; i += 4 * 256) {
+            const int n = i / S, s = i - n * S;
+            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * S + s);
+            s1 += (v.x + v.y) + (v.z + v.w);
+            s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (int i = b + (int)threadIdx.x; i < e; i += 256) {
+            const int n = i / S, s = i - n * S;
+            const float v = x[((size_t)n * C + c) * S + s];
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    const double t1 = block_sum_256<double>((double)s1, red);
+    const double t2 = block_sum_256<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        part[(size_t)c * slices + sl] = t1;
+        part[(size_t)(C + c) * slices + sl] = t2;
+    }
+}
+
+__global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C, int slices, double count,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         float momentum, float eps, float* __restrict__ scale,
+                                         float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < slices; ++k) {
+        s1 += part[(size_t)c * slices + k];
+        s2 += part[(size_t)(C + c) * slices + k];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = g * (float)invstd;
+    scale[c] = sc;
+    shift[c] = bt - (float)mean * sc;
+}
+
+__global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                     float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = bt - rm[c] * sc;
+}
+
+// ---- y = relu?(x*scale[c] + shift[c] + res?) ------------------------------------------
+// grid.x = row (n*C + c), grid.y = chunk of the row; 256 threads x 16 elements per chunk.
+constexpr int ROW_CHUNK = 4096;
+
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       float* __restrict__ y, int C, int S,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift) {
+    const int row = blockIdx.x;
+    const int c = row % C;
+    const float sc = scale[c], sh = shift[c];
+    const size_t base = (size_t)row * S;
+    const int s0 = blockIdx.y * ROW_CHUNK;
+    const int s1 = min(S, s0 + ROW_CHUNK);
+    if ((S % 4) == 0) {
+        for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            float4 v = *reinterpret_cast<const float4*>(x + base + s);
+            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            if (RES) {
+                const float4 r = *reinterpret_cast<const float4*>(res + base + s);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(y + base + s) = v;
+        }
+    } else {
+        for (int s = s0 + threadIdx.x; s < s1; s += 256) {
+            float v = x[base + s] * sc + sh;
+            if (RES) v += res[base + s];
+            if (RELU) v = fmaxf(v, 0.f);
+            y[base + s] = v;
+        }
+    }
+}
+
+// ---- backward reduce: sum g, sum g*xhat with g = dy * (y > 0 if RELU) -----------------
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ y, int N, int C, int S,
+                                                            int slices, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const bool vec = (S % 4) == 0;
+    int b, e;
+    slice_range(N * S, slices, sl, vec, b, e);
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    if (vec) {
+        for (int i = b + 4 * (int)threadIdx.x; i < e; i += 4 * 256) {
+            const int n = i / S, s = i - n * S;
+            const size_t off = ((size_t)n * C + c) * S + s;
+            float4 g = *reinterpret_cast<const float4*>(dy + off);
+            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + off);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            s1 += (g.x + g.y) + (g.z + g.w);
+            s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) +
+                  (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
+        }
+    } else {
+        for (int i = b + (int)threadIdx.x; i < e; i += 256) {
+            const int n = i / S, s = i - n * S;
+            const size_t off = ((size_t)n * C + c) * S + s;
+            float g = dy[off];
+            if (RELU) g = y[off] > 0.f ? g : 0.f;
+            s1 += g;
+            s2 += g * ((x[off] - mu) * is);
+        }
+    }
+    const double t1 = block_sum_256<double>((double)s1, red);
+    const double t2 = block_sum_256<double>((double)s2, red);
+    if (threadIdx.x == 0) {
+        part[(size_t)c * slices + sl] = t1;
+        part[(size_t)(C + c) * slices + sl] = t2;
+    }
+}
+
+// dgamma = sum g*xhat, dbeta = sum g;  dx = a*g + b*x + k  with
+//   a = gamma*invstd, b = -a*invstd*dgamma/M, k = -a*dbeta/M - b*mean
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int slices, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
+                                       float* __restrict__ ck) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgx = 0.0;
+    for (int k = 0; k < slices; ++k) {
+        sg += part[(size_t)c * slices + k];
+        sgx += part[(size_t)(C + c) * slices + k];
+    }
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)sg;
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    const double is = (double)invstd[c], mu = (double)mean[c];
+    const double a = g * is;
+    const double b = -a * is * sgx / count;
+    const double k = -a * sg / count - b * mu;
+    ca[c] = (float)a;
+    cb[c] = (float)b;
+    ck[c] = (float)k;
+}
+
+template <bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, float* __restrict__ dx,
+                                                           float* __restrict__ dres, int C, int S,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ ck) {
+    const int row = blockIdx.x;
+    const int c = row % C;
+    const float a = ca[c], b = cb[c], k = ck[c];
+    const size_t base = (size_t)row * S;
+    const int s0 = blockIdx.y * ROW_CHUNK;
+    const int s1 = min(S, s0 + ROW_CHUNK);
+    if ((S % 4) == 0) {
+        for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            float4 g = *reinterpret_cast<const float4*>(dy + base + s);
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
+            if (RELU) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + s);
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            if (DRES) *reinterpret_cast<float4*>(dres + base + s) = g;
+            float4 o;
+            o.x = a * g.x + b * xv.x + k; o.y = a * g.y + b * xv.y + k;
+            o.z = a * g.z + b * xv.z + k; o.w = a * g.w + b * xv.w + k;
+            *reinterpret_cast<float4*>(dx + base + s) = o;
+        }
+    } else {
+        for (int s = s0 + threadIdx.x; s < s1; s += 256) {
+            float g = dy[base + s];
+            if (RELU) g = y[base + s] > 0.f ? g : 0.f;
+            if (DRES) dres[base + s] = g;
+            dx[base + s] = a * g + b * x[base + s] + k;
+        }
+    }
+}
+
+static int check_ncs(int N, int C, int S) {
+    if (N <= 0 || C <= 0 || S <= 0) return ZSV_E_BAD_SHAPE;
+    if ((double)N * C * S >= 2147483647.0) return ZSV_E_TOO_LARGE;
+    return ZSV_OK;
+}
+
+static int launch_apply(const float* x, const float* res, float* y, int N, int C, int S, const float* scale,
+                        const float* shift, int relu, hipStream_t stream) {
+    const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
+    return launch_status();
+}
+
+}  // namespace zsv
+
+using namespace zsv;
+
+extern "C" size_t zsv_bn_workspace_bytes(int32_t N, int32_t C, int32_t S) {
+    if (check_ncs(N, C, S) != ZSV_OK) return 0;
+    return bn_ws_bytes(N, C, S);
+}
+
+extern "C" int zsv_bn_fwd_train(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
+                                const float* beta, const float* residual, int fuse_relu, float* y,
+                                float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream_) {
+    int st = check_ncs(N, C, S);
+    if (st) return st;
+    if (!x || !y || !save_mean || !save_invstd || !workspace) return ZSV_E_NULL;
+    if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int slices = bn_slices(N, C, S);
+    BnWs w = bn_ws(workspace, C, slices);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+    if ((st = launch_status())) return st;
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
+                       slices, (double)N * S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
+                       momentum, eps, w.scale, w.shift);
+    if ((st = launch_status())) return st;
+    return launch_apply(x, residual, y, N, C, S, w.scale, w.shift, fuse_relu, stream);
+}
+
+extern "C" int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma, const float* beta,
+                               const float* running_mean, const float* running_var, const float* residual,
+                               int fuse_relu, float eps, float* y, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+    int st = check_ncs(N, C, S);
+    if (st) return st;
+    if (!x || !y || !running_mean || !running_var || !workspace) return ZSV_E_NULL;
+    if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    BnWs w = bn_ws(workspace, C, bn_slices(N, C, S));
+    hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, C, gamma, beta, running_mean,
+                       running_var, eps, w.scale, w.shift);
+    if ((st = launch_status())) return st;
+    return launch_apply(x, residual, y, N, C, S, w.scale, w.shift, fuse_relu, stream);
+}
+
+extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
+                          const float* gamma, const float* save_mean, const float* save_invstd, int fuse_relu,
+                          float* dx, float* d_residual, float* dgamma, float* dbeta, void* workspace,
+                          size_t workspace_bytes, void* stream_) {
+    int st = check_ncs(N, C, S);
+    if (st) return st;
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !workspace) return ZSV_E_NULL;
+    if (fuse_relu && !y) return ZSV_E_NULL;
+    if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int slices = bn_slices(N, C, S);
+    BnWs w = bn_ws(workspace, C, slices);
+    if (fuse_relu)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(C, slices), dim3(256), 0, stream, dy, x, y, N, C, S, slices,
+                           save_mean, save_invstd, w.part);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(C, slices), dim3(256), 0, stream, dy, x, y, N, C, S, slices,
+                           save_mean, save_invstd, w.part);
+    if ((st = launch_status())) return st;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C, slices,
+                       (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1);
+    if ((st = launch_status())) return st;
+    const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
+    if (fuse_relu && d_residual)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
+    else if (fuse_relu)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
+    else if (d_residual)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
+    return launch_status();
+}

@@ -1,0 +1,295 @@
+// conv_wgrad.hip -- weight gradient of the 3-D convolution for gfx950 (MI355X).
+//
+// Supplies aten::convolution_backward's grad_weight for every Conv3d of the reference
+// (resnet.py:23-30,40-52,63-70,170,181,184,270; network.py:102-117) and, with S = 1,
+// the weight gradient of nn.Linear (network.py:611-616,120,132).
+//
+//   dW[co][k] = sum_p dY[co][p] * Xcol[k][p],   k = (ci, kt, kh, kw), p = (n, to, ho, wo)
+//
+// GEMM with the reduction over output voxels p (up to 1.1 M for layer1) and a small
+// output (Cout x Cin*taps).  MI355X mapping:
+//   * fp32 matrix core v_mfma_f32_16x16x4_f32 (bit-exact fp32), rows = Cout, columns = k;
+//   * the voxel range is cut into `slices` contiguous ranges (grid.y) so that a launch has
+//     >= ~1k workgroups even when the output has a handful of tiles; every slice writes
+//     its partial slab to the caller's workspace and a second kernel adds the slabs in
+//     slice order -> bitwise reproducible, no float atomics;
+//   * both operands are staged voxel-contiguous: dY rows are read straight along the
+//     contiguous S axis, Xcol rows are gathered on the fly (same per-voxel base offset +
+//     padding-mask scheme as the forward kernel), 32 voxels per chunk;
+//   * LDS images As[BM][LDK], Bs[BN][LDK] with LDK = 34 (== 2 mod 32): the MFMA operand
+//     fetch (16 rows x 2 voxels per 32-lane group) and the staging stores are both
+//     bank-conflict free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zsv_hip.h"
+#include "zsv_common.h"
+
+namespace zsv {
+
+int conv_check(const zsv_conv_desc* d);   // conv_igemm.hip
+
+struct WgradParams {
+    int M;            // Cout
+    int K;            // Cin * taps
+    int P;            // N * oS voxels
+    int taps, kHW, kW, kH, kT;
+    int oS, oHW, oW;  // dY geometry
+    int gC, gT, gH, gW, gS, gHW;   // x geometry
+    int sT, sH, sW, pT, pH, pW;
+    int chunks_per_slice;          // 32-voxel chunks handled by one slice
+};
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const float* __restrict__ X,
+                                                         const float* __restrict__ DY,
+                                                         float* __restrict__ OUT, int tiles_m) {
+    constexpr int BM = 16 * TM * WGM;
+    constexpr int BN = 16 * TN * WGN;
+    constexpr int BP = 32;                 // voxels per chunk
+    constexpr int LDK = BP + 2;
+    constexpr int RPP = 256 / BP;          // rows per staging pass (8)
+    constexpr int APASS = BM / RPP;
+    constexpr int BPASS = BN / RPP;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of 8");
+
+    __shared__ float As[2][BM * LDK];
+    __shared__ float Bs[2][BN * LDK];
+    __shared__ int kinfo[BN][2];           // per k-row: gather offset, packed shifts
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WGN) * (16 * TM);
+    const int wn0 = (wave % WGN) * (16 * TN);
+    const int m0 = (blockIdx.x % tiles_m) * BM;
+    const int n0 = (blockIdx.x / tiles_m) * BN;
+    const int slice = blockIdx.y;
+
+    // k-rows of this tile are fixed for the whole kernel: decode once
+    for (int r = tid; r < BN; r += 256) {
+        const int k = n0 + r;
+        int goff = 0, shifts = 31 | (31 << 8) | (31 << 16);
+        if (k < prm.K) {
+            const int c = k / prm.taps;
+            const int tap = k - c * prm.taps;
+            const int kt = tap / prm.kHW;
+            const int rr = tap - kt * prm.kHW;
+            const int kh = rr / prm.kW;
+            const int kw = rr - kh * prm.kW;
+            goff = c * prm.gS + kt * prm.gHW + kh * prm.gW + kw;
+            shifts = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
+        }
+        kinfo[r][0] = goff;
+        kinfo[r][1] = shifts;
+    }
+
+    const int pcol = tid % BP;
+    const int prow0 = tid / BP;
+    const int chunk_begin = slice * prm.chunks_per_slice;
+    int chunk_end = chunk_begin + prm.chunks_per_slice;
+    const int total_chunks = (prm.P + BP - 1) / BP;
+    if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+    float areg[APASS], breg[BPASS];
+
+    auto load_chunk = [&](int chunk) {
+        const int p = chunk * BP + pcol;
+        const bool pv = p < prm.P;
+        int dy_base = 0, x_base = 0;
+        unsigned vmask = 0;
+        if (pv) {
+            const int n = p / prm.oS;
+            int r = p - n * prm.oS;
+            dy_base = n * prm.M * prm.oS + r;
+            const int ot = r / prm.oHW;
+            r -= ot * prm.oHW;
+            const int oh = r / prm.oW;
+            const int ow = r - oh * prm.oW;
+            const int t0 = ot * prm.sT - prm.pT, h0 = oh * prm.sH - prm.pH, w0 = ow * prm.sW - prm.pW;
+            x_base = n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0;
+            for (int k = 0; k < prm.kW; ++k) vmask |= ((unsigned)(w0 + k) < (unsigned)prm.gW) << k;
+            for (int k = 0; k < prm.kH; ++k) vmask |= ((unsigned)(h0 + k) < (unsigned)prm.gH) << (8 + k);
+            for (int k = 0; k < prm.kT; ++k) vmask |= ((unsigned)(t0 + k) < (unsigned)prm.gT) << (16 + k);
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int row = prow0 + RPP * j;
+            const bool ok = pv && (m0 + row < prm.M);
+            const int off = ok ? dy_base + (m0 + row) * prm.oS : 0;
+            const float v = DY[off];
+            areg[j] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int row = prow0 + RPP * j;
+            const int goff = kinfo[row][0];
+            const int sh = kinfo[row][1];
+            const unsigned ok = (vmask >> (sh & 31)) & (vmask >> ((sh >> 8) & 31)) & (vmask >> ((sh >> 16) & 31)) & 1u;
+            const int off = ok ? x_base + goff : 0;
+            const float v = X[off];
+            breg[j] = ok ? v : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) As[buf][(prow0 + RPP * j) * LDK + pcol] = areg[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) Bs[buf][(prow0 + RPP * j) * LDK + pcol] = breg[j];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();   // kinfo visible
+    if (chunk_begin < chunk_end) {
+        load_chunk(chunk_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    const int frag_k = lane >> 4;
+    const int frag_r = lane & 15;
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+        const int cur = (ch - chunk_begin) & 1;
+        const bool more = (ch + 1) < chunk_end;
+        if (more) load_chunk(ch + 1);
+        const float* as = &As[cur][0];
+        const float* bs = &Bs[cur][0];
+#pragma unroll
+        for (int kk = 0; kk < BP / 4; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[(wm0 + 16 * i + frag_r) * LDK + kk * 4 + frag_k];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[(wn0 + 16 * j + frag_r) * LDK + kk * 4 + frag_k];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial slab of this slice: OUT[slice][m][k]
+    float* out = OUT + (size_t)slice * prm.M * prm.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn0 + 16 * j + frag_r;
+        if (k >= prm.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm0 + 16 * i + 4 * frag_k + r;
+                if (m < prm.M) out[(size_t)m * prm.K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// dw[i] = sum_s slab[s][i]  (slice order -> deterministic)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                       long n, int slices) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+struct WgradPlan {
+    int cfg;        // 0: 128x128, 1: 64x128 (small Cout), 2: 144x64
+    int tiles_m, tiles_n, slices, chunks_per_slice;
+};
+
+static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
+    WgradPlan pl;
+    const int M = d->Cout;
+    const int K = d->Cin * d->kT * d->kH * d->kW;
+    const long P = (long)d->N * d->To * d->Ho * d->Wo;
+    int bm, bn;
+    if (M <= 64) { pl.cfg = 1; bm = 64; bn = 128; }
+    else if (M % 144 == 0 || (M > 128 && M <= 144)) { pl.cfg = 2; bm = 144; bn = 64; }
+    else { pl.cfg = 0; bm = 128; bn = 128; }
+    pl.tiles_m = (M + bm - 1) / bm;
+    pl.tiles_n = (K + bn - 1) / bn;
+    const long chunks = (P + 31) / 32;
+    const long tiles = (long)pl.tiles_m * pl.tiles_n;
+    long slices = (1536 + tiles - 1) / tiles;            // aim at ~6 workgroups per CU
+    long max_slices = (chunks + 15) / 16;                // at least 16 chunks (512 voxels) per slice
+    if (max_slices < 1) max_slices = 1;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    if (slices > 1024) slices = 1024;
+    pl.chunks_per_slice = (int)((chunks + slices - 1) / slices);
+    pl.slices = (int)((chunks + pl.chunks_per_slice - 1) / pl.chunks_per_slice);
+    return pl;
+}
+
+}  // namespace zsv
+
+using namespace zsv;
+
+extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    const WgradPlan pl = wgrad_plan(d);
+    if (pl.slices <= 1) return 0;
+    return (size_t)pl.slices * d->Cout * d->Cin * d->kT * d->kH * d->kW * sizeof(float);
+}
+
+extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+    int st = conv_check(d);
+    if (st) return st;
+    if (!x || !dy || !dw) return ZSV_E_NULL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const WgradPlan pl = wgrad_plan(d);
+    const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
+
+    WgradParams p;
+    p.M = d->Cout;
+    p.taps = d->kT * d->kH * d->kW;
+    p.K = d->Cin * p.taps;
+    p.P = d->N * d->To * d->Ho * d->Wo;
+    p.kHW = d->kH * d->kW; p.kW = d->kW; p.kH = d->kH; p.kT = d->kT;
+    p.oS = d->To * d->Ho * d->Wo; p.oHW = d->Ho * d->Wo; p.oW = d->Wo;
+    p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
+    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
+    p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+    p.chunks_per_slice = pl.chunks_per_slice;
+
+    float* out = pl.slices > 1 ? (float*)workspace : dw;
+    const dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.slices);
+    switch (pl.cfg) {
+        case 0: hipLaunchKernelGGL((conv_wgrad_kernel<4, 4, 2, 2>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+        case 1: hipLaunchKernelGGL((conv_wgrad_kernel<4, 2, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+        default: hipLaunchKernelGGL((conv_wgrad_kernel<9, 1, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+    }
+    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (pl.slices > 1) {
+        const long n = (long)p.M * p.K;
+        long blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, pl.slices);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    }
+    return ZSV_OK;
+}
+
+extern "C" size_t zsv_linear_wgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {
+    zsv_conv_desc d = {rows, in_features, 1, 1, 1, out_features, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+    return zsv_conv3d_wgrad_workspace_bytes(&d);
+}
+
+extern "C" int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows, int32_t in_features,
+                                int32_t out_features, void* workspace, size_t workspace_bytes, void* stream) {
+    zsv_conv_desc d = {rows, in_features, 1, 1, 1, out_features, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+    return zsv_conv3d_wgrad(&d, x, dy, dw, workspace, workspace_bytes, stream);
+}

@@ -1,0 +1,322 @@
+// elementwise_pool.hip -- ReLU, residual add, pooling, channel sums and Adam for gfx950.
+//
+// HBM-bound passes that the reference reaches through torch.nn:
+//   relu        nn.ReLU / F.relu          resnet.py:49,95,98  network.py:147-166,614
+//   add_relu    out += residual; relu     resnet.py:110-111
+//   meanpool    torch.mean(f,(2,3,4))     network.py:595 (AdaptiveAvgPool3d resnet.py:251)
+//   maxpool3d   nn.MaxPool3d              network.py:103-118 (C3D)
+//   channel_sum bias gradient             network.py:102-117 convs, nn.Linear biases
+//   adam        torch.optim.Adam.step     main.py:131,200
+// Everything is float4-wide along the contiguous axis where alignment allows, grid-strided
+// with at most 2048 workgroups (8 per CU), reductions use 64-lane wave shuffles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zsv_hip.h"
+#include "zsv_common.h"
+
+namespace zsv {
+
+static inline unsigned ew_blocks(long work_items) {
+    long b = (work_items + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int OP>   // 0 relu fwd (a), 1 relu bwd (a = dy, b = y), 2 add_relu (a + b)
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long n, int vec) {
+    const long stride = (long)gridDim.x * 256;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 x = reinterpret_cast<const float4*>(a)[i];
+            float4 r;
+            if (OP == 0) {
+                r = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+            } else {
+                const float4 y = reinterpret_cast<const float4*>(b)[i];
+                if (OP == 1)
+                    r = make_float4(y.x > 0.f ? x.x : 0.f, y.y > 0.f ? x.y : 0.f, y.z > 0.f ? x.z : 0.f, y.w > 0.f ? x.w : 0.f);
+                else
+                    r = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+            }
+            reinterpret_cast<float4*>(out)[i] = r;
+        }
+        for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float x = a[i];
+            out[i] = OP == 0 ? fmaxf(x, 0.f) : (OP == 1 ? (b[i] > 0.f ? x : 0.f) : fmaxf(x + b[i], 0.f));
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float x = a[i];
+            out[i] = OP == 0 ? fmaxf(x, 0.f) : (OP == 1 ? (b[i] > 0.f ? x : 0.f) : fmaxf(x + b[i], 0.f));
+        }
+    }
+}
+
+// one wave per (n, c) row: mean over S
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const float* __restrict__ x, int rows, int S,
+                                                           float* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* p = x + (size_t)row * S;
+    float s = 0.f;
+    for (int i = lane; i < S; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s / (float)S;
+}
+
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dy, long total, int S,
+                                                           float* __restrict__ dx) {
+    const float inv = 1.f / (float)S;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        dx[i] = dy[i / S] * inv;
+}
+
+struct PoolGeom {
+    int Ti, Hi, Wi, To, Ho, Wo, kT, kH, kW, pT, pH, pW;
+};
+
+// one thread per output voxel; scan order (t, h, w), first maximum wins, NaN propagates
+// (same rule as aten's max_pool3d_with_indices)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, long total_out, PoolGeom g,
+                                                          float* __restrict__ y, int* __restrict__ arg) {
+    const int oS = g.To * g.Ho * g.Wo;
+    const int iS = g.Ti * g.Hi * g.Wi;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total_out; o += (long)gridDim.x * 256) {
+        const long row = o / oS;
+        int r = (int)(o - row * oS);
+        const int ot = r / (g.Ho * g.Wo);
+        r -= ot * g.Ho * g.Wo;
+        const int oh = r / g.Wo, ow = r - oh * g.Wo;
+        const float* p = x + row * iS;
+        float best = -INFINITY;
+        int besti = -1;
+        for (int a = 0; a < g.kT; ++a) {
+            const int t = ot * g.kT - g.pT + a;
+            if ((unsigned)t >= (unsigned)g.Ti) continue;
+            for (int b = 0; b < g.kH; ++b) {
+                const int h = oh * g.kH - g.pH + b;
+                if ((unsigned)h >= (unsigned)g.Hi) continue;
+                for (int c = 0; c < g.kW; ++c) {
+                    const int w = ow * g.kW - g.pW + c;
+                    if ((unsigned)w >= (unsigned)g.Wi) continue;
+                    const int idx = (t * g.Hi + h) * g.Wi + w;
+                    const float v = p[idx];
+                    if (besti < 0) besti = idx;           // aten starts at the window's first voxel
+                    if (v > best || v != v) { best = v; besti = idx; }
+                }
+            }
+        }
+        y[o] = best;
+        arg[o] = besti;
+    }
+}
+
+// windows do not overlap (kernel == stride): every input voxel belongs to at most one
+// window, so dx is a gather -- no atomics
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                                          long total_in, PoolGeom g, float* __restrict__ dx) {
+    const int oS = g.To * g.Ho * g.Wo;
+    const int iS = g.Ti * g.Hi * g.Wi;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_in; i += (long)gridDim.x * 256) {
+        const long row = i / iS;
+        const int idx = (int)(i - row * iS);
+        int r = idx;
+        const int t = r / (g.Hi * g.Wi);
+        r -= t * g.Hi * g.Wi;
+        const int h = r / g.Wi, w = r - h * g.Wi;
+        const int ot = (t + g.pT) / g.kT, oh = (h + g.pH) / g.kH, ow = (w + g.pW) / g.kW;
+        float v = 0.f;
+        if (ot < g.To && oh < g.Ho && ow < g.Wo) {
+            const long o = row * oS + (long)(ot * g.Ho + oh) * g.Wo + ow;
+            if (arg[o] == idx) v = dy[o];
+        }
+        dx[i] = v;
+    }
+}
+
+// channel sum over (n, s): partial per (c, slice) in double, then a fixed-order combine
+static inline int cs_slices(int N, int C, int S) {
+    const long per = (long)N * S;
+    long s = (1024 + C - 1) / C;
+    long mx = (per + 1023) / 1024;
+    if (mx < 1) mx = 1;
+    if (s > mx) s = mx;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, int N, int C, int S,
+                                                          int slices, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const int total = N * S;
+    const int len = (total + slices - 1) / slices;
+    const int b = sl * len;
+    const int e = min(total, b + len);
+    float s1 = 0.f;
+    for (int i = b + (int)threadIdx.x; i < e; i += 256) {
+        const int n = i / S, s = i - n * S;
+        s1 += dy[((size_t)n * C + c) * S + s];
+    }
+    const double t = block_sum_256<double>((double)s1, red);
+    if (threadIdx.x == 0) part[(size_t)c * slices + sl] = t;
+}
+
+__global__ void channel_sum_final_kernel(const double* __restrict__ part, int C, int slices, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < slices; ++k) s += part[(size_t)c * slices + k];
+    out[c] = (float)s;
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay), single-tensor formulation:
+//   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float b1,
+                                                   float b2, float eps, float step_size, float inv_sqrt_bc2) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+}  // namespace zsv
+
+using namespace zsv;
+
+extern "C" int zsv_relu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y) return ZSV_E_NULL;
+    if (n <= 0) return n == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    const int vec = aligned16(x) && aligned16(y);
+    hipLaunchKernelGGL((ew_kernel<0>), dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream, x, nullptr, y, (long)n, vec);
+    return launch_status();
+}
+
+extern "C" int zsv_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    if (!dy || !y || !dx) return ZSV_E_NULL;
+    if (n <= 0) return n == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    const int vec = aligned16(dy) && aligned16(y) && aligned16(dx);
+    hipLaunchKernelGGL((ew_kernel<1>), dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (long)n, vec);
+    return launch_status();
+}
+
+extern "C" int zsv_add_relu_fwd(const float* a, const float* b, float* y, int64_t n, void* stream) {
+    if (!a || !b || !y) return ZSV_E_NULL;
+    if (n <= 0) return n == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    const int vec = aligned16(a) && aligned16(b) && aligned16(y);
+    hipLaunchKernelGGL((ew_kernel<2>), dim3(ew_blocks(vec ? n / 4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n, vec);
+    return launch_status();
+}
+
+extern "C" int zsv_meanpool_fwd(const float* x, int32_t N, int32_t C, int32_t S, float* y, void* stream) {
+    if (!x || !y) return ZSV_E_NULL;
+    if (N <= 0 || C <= 0 || S <= 0) return ZSV_E_BAD_SHAPE;
+    const int rows = N * C;
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, rows, S, y);
+    return launch_status();
+}
+
+extern "C" int zsv_meanpool_bwd(const float* dy, int32_t N, int32_t C, int32_t S, float* dx, void* stream) {
+    if (!dy || !dx) return ZSV_E_NULL;
+    if (N <= 0 || C <= 0 || S <= 0) return ZSV_E_BAD_SHAPE;
+    const long total = (long)N * C * S;
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, total, S, dx);
+    return launch_status();
+}
+
+static int pool_geom(PoolGeom& g, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT, int32_t kH, int32_t kW, int32_t pT,
+                     int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo) {
+    if (Ti <= 0 || Hi <= 0 || Wi <= 0 || kT <= 0 || kH <= 0 || kW <= 0 || pT < 0 || pH < 0 || pW < 0) return ZSV_E_BAD_SHAPE;
+    if (2 * pT > kT || 2 * pH > kH || 2 * pW > kW) return ZSV_E_BAD_SHAPE;   // torch: pad <= kernel/2
+    // floor mode, stride == kernel
+    if (To != (Ti + 2 * pT - kT) / kT + 1 || Ho != (Hi + 2 * pH - kH) / kH + 1 || Wo != (Wi + 2 * pW - kW) / kW + 1)
+        return ZSV_E_BAD_SHAPE;
+    g = PoolGeom{Ti, Hi, Wi, To, Ho, Wo, kT, kH, kW, pT, pH, pW};
+    return ZSV_OK;
+}
+
+extern "C" int zsv_maxpool3d_fwd(const float* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT,
+                                 int32_t kH, int32_t kW, int32_t pT, int32_t pH, int32_t pW, int32_t To, int32_t Ho,
+                                 int32_t Wo, float* y, int32_t* argmax, void* stream) {
+    if (!x || !y || !argmax) return ZSV_E_NULL;
+    PoolGeom g;
+    int st = pool_geom(g, Ti, Hi, Wi, kT, kH, kW, pT, pH, pW, To, Ho, Wo);
+    if (st) return st;
+    if (N <= 0 || C <= 0) return ZSV_E_BAD_SHAPE;
+    const long total = (long)N * C * To * Ho * Wo;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, total, g, y, argmax);
+    return launch_status();
+}
+
+extern "C" int zsv_maxpool3d_bwd(const float* dy, const int32_t* argmax, int32_t N, int32_t C, int32_t Ti, int32_t Hi,
+                                 int32_t Wi, int32_t kT, int32_t kH, int32_t kW, int32_t pT, int32_t pH, int32_t pW,
+                                 int32_t To, int32_t Ho, int32_t Wo, float* dx, void* stream) {
+    if (!dy || !argmax || !dx) return ZSV_E_NULL;
+    PoolGeom g;
+    int st = pool_geom(g, Ti, Hi, Wi, kT, kH, kW, pT, pH, pW, To, Ho, Wo);
+    if (st) return st;
+    if (N <= 0 || C <= 0) return ZSV_E_BAD_SHAPE;
+    const long total = (long)N * C * Ti * Hi * Wi;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, total, g, dx);
+    return launch_status();
+}
+
+extern "C" size_t zsv_channel_sum_workspace_bytes(int32_t N, int32_t C, int32_t S) {
+    if (N <= 0 || C <= 0 || S <= 0) return 0;
+    return (size_t)C * cs_slices(N, C, S) * sizeof(double);
+}
+
+extern "C" int zsv_channel_sum(const float* dy, int32_t N, int32_t C, int32_t S, float* db, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+    if (!dy || !db || !workspace) return ZSV_E_NULL;
+    if (N <= 0 || C <= 0 || S <= 0) return ZSV_E_BAD_SHAPE;
+    if ((double)N * C * S >= 2147483647.0) return ZSV_E_TOO_LARGE;
+    if (workspace_bytes < zsv_channel_sum_workspace_bytes(N, C, S)) return ZSV_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int slices = cs_slices(N, C, S);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, slices), dim3(256), 0, stream, dy, N, C, S, slices, (double*)workspace);
+    int st = launch_status();
+    if (st) return st;
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)workspace, C, slices, db);
+    return launch_status();
+}
+
+extern "C" int zsv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, int32_t step, void* stream) {
+    if (!p || !g || !exp_avg || !exp_avg_sq) return ZSV_E_NULL;
+    if (n <= 0 || step <= 0) return n == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq, (long)n,
+                       beta1, beta2, eps, step_size, inv_sqrt_bc2);
+    return launch_status();
+}
+
+extern "C" const char* zsv_status_string(int status) {
+    switch (status) {
+        case ZSV_OK: return "ok";
+        case ZSV_E_BAD_SHAPE: return "bad shape / inconsistent geometry";
+        case ZSV_E_NULL: return "required pointer is NULL";
+        case ZSV_E_WORKSPACE: return "workspace too small";
+        case ZSV_E_TOO_LARGE: return "tensor has >= 2^31 elements";
+        case ZSV_E_LAUNCH: return "kernel launch failed";
+        case ZSV_E_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* zsv_version(void) { return "zsv_hip gfx950 " __DATE__; }

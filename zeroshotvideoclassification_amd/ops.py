@@ -1,0 +1,440 @@
+"""Autograd bindings of the gfx950 kernels (``libzsv_hip.so``) -- the only compute path.
+
+Every function here takes HIP-resident fp32 tensors, allocates outputs / workspaces with
+torch (the C ABI never allocates) and launches on the current HIP stream.  Backward is a
+``torch.autograd.Function`` per op calling the matching ``*_dgrad / *_wgrad / *_bwd`` entry
+point.  A CPU tensor, a non-fp32 tensor or a missing library raises ``RuntimeError``.
+
+What each op replaces in the reference is cited next to it.
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_void_p
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ConvDesc
+
+
+def _triple(v) -> Tuple[int, int, int]:
+    if isinstance(v, int):
+        return (v, v, v)
+    v = tuple(int(a) for a in v)
+    if len(v) == 1:
+        return (v[0],) * 3
+    if len(v) != 3:
+        raise ValueError(f"expected an int or 3 ints, got {v}")
+    return v
+
+
+def _require(*tensors: Optional[torch.Tensor]) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "zeroshotvideoclassification_amd ops run only on an MI355X HIP device; got a "
+                f"{t.device} tensor (there is no CPU fallback -- the CPU oracle lives in oracle/)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"fp32 tensors expected, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    if nbytes <= 0:
+        return None
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def conv_desc(x_shape: Sequence[int], w_shape: Sequence[int], stride, padding) -> ConvDesc:
+    n, cin, ti, hi, wi = (int(v) for v in x_shape)
+    cout, cin_w, kt, kh, kw = (int(v) for v in w_shape)
+    if cin != cin_w:
+        raise RuntimeError(f"conv3d: input has {cin} channels, weight expects {cin_w}")
+    st, sh, sw = _triple(stride)
+    pt, ph, pw = _triple(padding)
+    to = (ti + 2 * pt - kt) // st + 1
+    ho = (hi + 2 * ph - kh) // sh + 1
+    wo = (wi + 2 * pw - kw) // sw + 1
+    if min(to, ho, wo) <= 0:
+        raise RuntimeError(f"conv3d: kernel {(kt, kh, kw)} does not fit input {(ti, hi, wi)}")
+    return ConvDesc(n, cin, ti, hi, wi, cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
+
+
+# ------------------------------------------------------------------------------------------
+class _Conv3d(Function):
+    """aten::conv3d fwd / dgrad / wgrad (resnet.py:23-30,40-52,63-70,170,181,184,270;
+    network.py:102-117), optional bias and fused ReLU (network.py:147-162)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, relu):
+        _require(x, weight, bias)
+        if x.dim() != 5 or weight.dim() != 5:
+            raise RuntimeError("conv3d expects (N,C,T,H,W) input and (O,I,kT,kH,kW) weight")
+        x = x.contiguous()
+        weight = weight.contiguous()
+        d = conv_desc(x.shape, weight.shape, stride, padding)
+        y = torch.empty((d.N, d.Cout, d.To, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zsv_conv3d_fwd(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
+                                          1 if relu else 0, _stream()), "zsv_conv3d_fwd")
+        ctx.desc = d
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        d = ctx.desc
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = dw = db = None
+        with torch.cuda.device(dy.device):
+            if ctx.relu:
+                g = torch.empty_like(dy)
+                _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
+                dy = g
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _stream()),
+                           "zsv_conv3d_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
+                ws = _workspace(nbytes, dy.device)
+                _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
+                                                _stream()), "zsv_conv3d_wgrad")
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = channel_sum(dy)
+        return dx, dw, db, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False):
+    return _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu))
+
+
+def channel_sum(t: torch.Tensor) -> torch.Tensor:
+    """sum over every axis but the channel axis 1 of an (N, C, ...) tensor (bias gradients)."""
+    _require(t)
+    t = t.contiguous()
+    n, c = int(t.shape[0]), int(t.shape[1])
+    s = t.numel() // (n * c)
+    lib = _lib.load()
+    out = torch.empty(c, dtype=torch.float32, device=t.device)
+    nbytes = lib.zsv_channel_sum_workspace_bytes(n, c, s)
+    ws = _workspace(nbytes, t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(lib.zsv_channel_sum(t.data_ptr(), n, c, s, out.data_ptr(), _ptr(ws), nbytes, _stream()),
+                   "zsv_channel_sum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+class _BatchNormAct(Function):
+    """nn.BatchNorm3d (resnet.py:48,95,97,183,186,272) + optional `out += residual`
+    (resnet.py:110) + optional ReLU (resnet.py:49,95,111) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
+        _require(x, gamma, beta, running_mean, running_var, residual)
+        x = x.contiguous()
+        n, c = int(x.shape[0]), int(x.shape[1])
+        s = x.numel() // (n * c)
+        if residual is not None:
+            if residual.shape != x.shape:
+                raise RuntimeError(f"residual shape {tuple(residual.shape)} != {tuple(x.shape)}")
+            residual = residual.contiguous()
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
+        ws = _workspace(nbytes, x.device)
+        ctx.training = bool(training)
+        with torch.cuda.device(x.device):
+            if training:
+                save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+                save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+                _lib.check(lib.zsv_bn_fwd_train(x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), _ptr(residual),
+                                                1 if relu else 0, y.data_ptr(), save_mean.data_ptr(),
+                                                save_invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                float(momentum), float(eps), _ptr(ws), nbytes, _stream()),
+                           "zsv_bn_fwd_train")
+            else:
+                if running_mean is None or running_var is None:
+                    raise RuntimeError("eval-mode BatchNorm needs running statistics")
+                save_mean = save_invstd = None
+                _lib.check(lib.zsv_bn_fwd_eval(x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), running_mean.data_ptr(),
+                                               running_var.data_ptr(), _ptr(residual), 1 if relu else 0, float(eps),
+                                               y.data_ptr(), _ptr(ws), nbytes, _stream()), "zsv_bn_fwd_eval")
+        ctx.relu = bool(relu)
+        ctx.has_res = residual is not None
+        ctx.dims = (n, c, s)
+        ctx.save_for_backward(x, gamma, save_mean, save_invstd, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not part of the hot path "
+                               "(the reference evaluates under torch.no_grad(), main.py:230)")
+        x, gamma, save_mean, save_invstd, y = ctx.saved_tensors
+        n, c, s = ctx.dims
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        want_res = ctx.has_res and ctx.needs_input_grad[5]
+        # without a fused ReLU the residual gradient is dy itself
+        dres = torch.empty_like(x) if (want_res and ctx.relu) else None
+        nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
+        ws = _workspace(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zsv_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), n, c, s, _ptr(gamma), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), _ptr(dres),
+                                      dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
+        if want_res and not ctx.relu:
+            dres = dy
+        return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if ctx.needs_input_grad[2] else None, None, None, dres if want_res else None,
+                None, None, None, None)
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, training=True, momentum=0.1,
+                   eps=1e-5, relu=False):
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
+                               float(eps), bool(relu))
+
+
+def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False):
+    """Apply an ``nn.BatchNorm3d``-like module's parameters through the fused kernel, with
+    torch's train/eval and running-statistics semantics (momentum=None -> cumulative average
+    is not used anywhere in the reference and is rejected)."""
+    if bn.momentum is None:
+        raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
+    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
+    rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
+    return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu)
+
+
+# ------------------------------------------------------------------------------------------
+class _ReLU(Function):
+    """nn.ReLU / F.relu (resnet.py:49,95,98)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().zsv_relu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "zsv_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _stream()),
+                       "zsv_relu_bwd")
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+class _AddReLU(Function):
+    """`out += residual; out = relu(out)` (resnet.py:110-111) when no BatchNorm precedes it."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require(a, b)
+        if a.shape != b.shape:
+            raise RuntimeError("add_relu: shapes differ")
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _lib.check(_lib.load().zsv_add_relu_fwd(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()),
+                       "zsv_add_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream()),
+                       "zsv_relu_bwd")
+        return g, g
+
+
+def add_relu(a, b):
+    return _AddReLU.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------
+class _MeanPool(Function):
+    """torch.mean(f, dim=(2,3,4)) (network.py:595) == AdaptiveAvgPool3d(1).flatten(1) (resnet.py:251-253)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x)
+        x = x.contiguous()
+        n, c = int(x.shape[0]), int(x.shape[1])
+        s = x.numel() // (n * c)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().zsv_meanpool_fwd(x.data_ptr(), n, c, s, y.data_ptr(), _stream()), "zsv_meanpool_fwd")
+        ctx.shape = tuple(x.shape)
+        ctx.dims = (n, c, s)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, c, s = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().zsv_meanpool_bwd(dy.data_ptr(), n, c, s, dx.data_ptr(), _stream()), "zsv_meanpool_bwd")
+        return dx
+
+
+def mean_pool(x):
+    return _MeanPool.apply(x)
+
+
+class _MaxPool3d(Function):
+    """nn.MaxPool3d with kernel == stride (network.py:103-118)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, padding):
+        _require(x)
+        x = x.contiguous()
+        n, c, ti, hi, wi = (int(v) for v in x.shape)
+        kt, kh, kw = kernel
+        pt, ph, pw = padding
+        to, ho, wo = (ti + 2 * pt - kt) // kt + 1, (hi + 2 * ph - kh) // kh + 1, (wi + 2 * pw - kw) // kw + 1
+        y = torch.empty((n, c, to, ho, wo), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n, c, to, ho, wo), dtype=torch.int32, device=x.device)
+        geom = (n, c, ti, hi, wi, kt, kh, kw, pt, ph, pw, to, ho, wo)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().zsv_maxpool3d_fwd(x.data_ptr(), *geom, y.data_ptr(), arg.data_ptr(), _stream()),
+                       "zsv_maxpool3d_fwd")
+        ctx.geom = geom
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        geom = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty(geom[:5], dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(_lib.load().zsv_maxpool3d_bwd(dy.data_ptr(), arg.data_ptr(), *geom, dx.data_ptr(), _stream()),
+                       "zsv_maxpool3d_bwd")
+        return dx, None, None
+
+
+def max_pool3d(x, kernel_size, stride=None, padding=0):
+    k = _triple(kernel_size)
+    s = k if stride is None else _triple(stride)
+    if s != k:
+        raise RuntimeError("max_pool3d: only kernel_size == stride is implemented (all the reference uses)")
+    return _MaxPool3d.apply(x, k, _triple(padding))
+
+
+# ------------------------------------------------------------------------------------------
+class _Linear(Function):
+    """nn.Linear (network.py:611-616 MLP; :120,132 fc6 / regressor) on the MFMA GEMM core."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        _require(x, weight, bias)
+        if x.dim() != 2:
+            raise RuntimeError("linear expects a (rows, in_features) input")
+        x, weight = x.contiguous(), weight.contiguous()
+        rows, fin = int(x.shape[0]), int(x.shape[1])
+        fout = int(weight.shape[0])
+        if int(weight.shape[1]) != fin:
+            raise RuntimeError("linear: in_features mismatch")
+        y = torch.empty((rows, fout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().zsv_linear_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), rows, fin,
+                                                  fout, 1 if relu else 0, _stream()), "zsv_linear_fwd")
+        ctx.dims = (rows, fin, fout)
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        rows, fin, fout = ctx.dims
+        lib = _lib.load()
+        dy = dy.contiguous()
+        dx = dw = db = None
+        with torch.cuda.device(dy.device):
+            if ctx.relu:
+                g = torch.empty_like(dy)
+                _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
+                dy = g
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(lib.zsv_linear_dgrad(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), rows, fin, fout,
+                                                _stream()), "zsv_linear_dgrad")
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                nbytes = lib.zsv_linear_wgrad_workspace_bytes(rows, fin, fout)
+                ws = _workspace(nbytes, dy.device)
+                _lib.check(lib.zsv_linear_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), rows, fin, fout, _ptr(ws),
+                                                nbytes, _stream()), "zsv_linear_wgrad")
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = channel_sum(dy)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    return _Linear.apply(x, weight, bias, bool(relu))
+
+
+def adam_step_(p: torch.Tensor, g: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
+               lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    """In-place torch.optim.Adam update (main.py:131) of a flat fp32 buffer."""
+    _require(p, g, exp_avg, exp_avg_sq)
+    for t in (p, g, exp_avg, exp_avg_sq):
+        if not t.is_contiguous() or t.numel() != p.numel():
+            raise RuntimeError("adam_step_: flat contiguous buffers of equal size expected")
+    with torch.cuda.device(p.device):
+        _lib.check(_lib.load().zsv_adam_step(p.data_ptr(), g.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                             p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                             int(step), _stream()), "zsv_adam_step")

@@ -1,0 +1,254 @@
+"""MI355X-native video ResNets behind the reference's ``resnet.py`` surface.
+
+Drop-in for the reference module of the same name (``import resnet as models``,
+network.py:5): identical public names, constructor signatures, attribute tree and
+``state_dict`` keys; ``VideoResNet.forward`` returns ``(pooled, layer4_features)`` like the
+fork does (resnet.py:243-256).  All arithmetic runs in the hand-written gfx950 kernels
+(``ops``): the containers below do not call their children one by one -- they launch the
+fused sequences the hardware wants:
+
+    conv (MFMA implicit GEMM)  ->  BatchNorm statistics  ->  normalise + residual + ReLU
+                                                             in a single HBM pass
+
+* ``Conv2Plus1D``        resnet.py:37-57    spatial 1x3x3 -> BN+ReLU (fused) -> temporal 3x1x1
+* ``BasicBlock``         resnet.py:79-113   ... -> BN + ``out += residual`` + ReLU fused
+* ``R2Plus1dStem`` / ``BasicStem``  resnet.py:165-187
+* ``VideoResNet``        resnet.py:190-281, factories resnet.py:293-362
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, List, Optional, Sequence, Tuple, Type, Union
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .layers import AdaptiveAvgPool3d, BatchNorm3d, Conv3d, Linear, ReLU
+
+__all__ = ["r3d_18", "mc3_18", "r2plus1d_18"]
+
+
+def _run_chain(mods: Sequence[nn.Module], x: Tensor) -> Tensor:
+    """Run conv / BN / ReLU children with BN+ReLU pairs fused into one kernel sequence."""
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, BatchNorm3d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            x = m(x, relu=True)
+            i += 2
+        elif isinstance(m, _FusedSequential):
+            x = m(x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+class _FusedSequential(nn.Sequential):
+    def forward(self, x: Tensor) -> Tensor:
+        return _run_chain(list(self), x)
+
+
+class Conv3DSimple(Conv3d):
+    """3x3x3 convolution, stride s in every axis (resnet.py:18-34)."""
+
+    def __init__(self, in_planes: int, out_planes: int, midplanes: Optional[int] = None, stride: int = 1,
+                 padding: int = 1) -> None:
+        super().__init__(in_planes, out_planes, kernel_size=(3, 3, 3), stride=stride, padding=padding, bias=False)
+
+    @staticmethod
+    def get_downsample_stride(stride: int) -> Tuple[int, int, int]:
+        return stride, stride, stride
+
+
+class Conv3DNoTemporal(Conv3d):
+    """1x3x3 convolution, spatial stride only (resnet.py:60-76)."""
+
+    def __init__(self, in_planes: int, out_planes: int, midplanes: Optional[int] = None, stride: int = 1,
+                 padding: int = 1) -> None:
+        super().__init__(in_planes, out_planes, kernel_size=(1, 3, 3), stride=(1, stride, stride),
+                         padding=(0, padding, padding), bias=False)
+
+    @staticmethod
+    def get_downsample_stride(stride: int) -> Tuple[int, int, int]:
+        return 1, stride, stride
+
+
+class Conv2Plus1D(_FusedSequential):
+    """Factorised (2+1)D convolution (resnet.py:37-57): children 0..3 are the spatial conv, its
+    BatchNorm, ReLU, and the temporal conv -- same indices, hence same ``state_dict`` keys."""
+
+    def __init__(self, in_planes: int, out_planes: int, midplanes: int, stride: int = 1, padding: int = 1) -> None:
+        super().__init__(
+            Conv3d(in_planes, midplanes, kernel_size=(1, 3, 3), stride=(1, stride, stride),
+                   padding=(0, padding, padding), bias=False),
+            BatchNorm3d(midplanes),
+            ReLU(inplace=True),
+            Conv3d(midplanes, out_planes, kernel_size=(3, 1, 1), stride=(stride, 1, 1),
+                   padding=(padding, 0, 0), bias=False),
+        )
+
+    @staticmethod
+    def get_downsample_stride(stride: int) -> Tuple[int, int, int]:
+        return stride, stride, stride
+
+
+def _midplanes(inplanes: int, planes: int) -> int:
+    # parameter-matching width of the factorised pair (resnet.py:91)
+    return (inplanes * planes * 3 * 3 * 3) // (inplanes * 3 * 3 + 3 * planes)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, conv_builder: Callable[..., nn.Module], stride: int = 1,
+                 downsample: Optional[nn.Module] = None) -> None:
+        super().__init__()
+        mid = _midplanes(inplanes, planes)
+        self.conv1 = _FusedSequential(conv_builder(inplanes, planes, mid, stride), BatchNorm3d(planes),
+                                      ReLU(inplace=True))
+        self.conv2 = _FusedSequential(conv_builder(planes, planes, mid), BatchNorm3d(planes))
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.conv1(x)
+        out = self.conv2[0](out)
+        residual = x if self.downsample is None else self.downsample(x)
+        tail = self.conv2[1]
+        if len(self.conv2) == 2 and isinstance(tail, BatchNorm3d):
+            # BN + `out += residual` + ReLU (resnet.py:97,110-111) in one pass
+            return tail(out, residual=residual, relu=True)
+        out = _run_chain(list(self.conv2)[1:], out)
+        return ops.add_relu(out, residual)
+
+
+class Bottleneck(nn.Module):
+    """Present for surface completeness (resnet.py:116-162); no factory in the reference uses it."""
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, conv_builder: Callable[..., nn.Module], stride: int = 1,
+                 downsample: Optional[nn.Module] = None) -> None:
+        super().__init__()
+        mid = _midplanes(inplanes, planes)
+        self.conv1 = _FusedSequential(Conv3d(inplanes, planes, kernel_size=1, bias=False), BatchNorm3d(planes),
+                                      ReLU(inplace=True))
+        self.conv2 = _FusedSequential(conv_builder(planes, planes, mid, stride), BatchNorm3d(planes),
+                                      ReLU(inplace=True))
+        self.conv3 = _FusedSequential(Conv3d(planes, planes * self.expansion, kernel_size=1, bias=False),
+                                      BatchNorm3d(planes * self.expansion))
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.conv2(self.conv1(x))
+        out = self.conv3[0](out)
+        residual = x if self.downsample is None else self.downsample(x)
+        return self.conv3[1](out, residual=residual, relu=True)
+
+
+class BasicStem(_FusedSequential):
+    """conv 3x7x7 / (1,2,2) -> BN -> ReLU (resnet.py:165-173)."""
+
+    def __init__(self) -> None:
+        super().__init__(
+            Conv3d(3, 64, kernel_size=(3, 7, 7), stride=(1, 2, 2), padding=(1, 3, 3), bias=False),
+            BatchNorm3d(64), ReLU(inplace=True))
+
+
+class R2Plus1dStem(_FusedSequential):
+    """conv 1x7x7 / (1,2,2) -> BN -> ReLU -> conv 3x1x1 -> BN -> ReLU (resnet.py:176-187)."""
+
+    def __init__(self) -> None:
+        super().__init__(
+            Conv3d(3, 45, kernel_size=(1, 7, 7), stride=(1, 2, 2), padding=(0, 3, 3), bias=False),
+            BatchNorm3d(45), ReLU(inplace=True),
+            Conv3d(45, 64, kernel_size=(3, 1, 1), stride=(1, 1, 1), padding=(1, 0, 0), bias=False),
+            BatchNorm3d(64), ReLU(inplace=True))
+
+
+class VideoResNet(nn.Module):
+    def __init__(self, block: Type[Union[BasicBlock, Bottleneck]],
+                 conv_makers: Sequence[Type[Union[Conv3DSimple, Conv3DNoTemporal, Conv2Plus1D]]],
+                 layers: List[int], stem: Callable[..., nn.Module], num_classes: int = 400,
+                 zero_init_residual: bool = False) -> None:
+        super().__init__()
+        self.inplanes = 64
+        self.stem = stem()
+        for i, (planes, stride) in enumerate([(64, 1), (128, 2), (256, 2), (512, 2)]):   # resnet.py:217-220
+            setattr(self, f"layer{i + 1}", self._make_layer(block, conv_makers[i], planes, layers[i], stride=stride))
+        self.avgpool = AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = Linear(512 * block.expansion, num_classes)      # built but never applied (resnet.py:254)
+        self._init_weights(zero_init_residual)
+
+    def _init_weights(self, zero_init_residual: bool) -> None:
+        # resnet.py:226-241
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.zeros_(m.bias)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.conv3[1].weight)
+
+    def forward(self, x: Tensor):
+        x = self.stem(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        f = self.layer4(x)
+        pooled = ops.mean_pool(f)          # avgpool + flatten(1); `fc` is skipped by the fork
+        return pooled, f
+
+    def _make_layer(self, block, conv_builder, planes: int, blocks: int, stride: int = 1) -> nn.Sequential:
+        downsample = None
+        out_planes = planes * block.expansion
+        if stride != 1 or self.inplanes != out_planes:                      # resnet.py:268-273
+            downsample = _FusedSequential(
+                Conv3d(self.inplanes, out_planes, kernel_size=1, stride=conv_builder.get_downsample_stride(stride),
+                       bias=False),
+                BatchNorm3d(out_planes))
+        stack = [block(self.inplanes, planes, conv_builder, stride, downsample)]
+        self.inplanes = out_planes
+        stack += [block(self.inplanes, planes, conv_builder) for _ in range(1, blocks)]
+        return nn.Sequential(*stack)
+
+
+def _video_resnet(arch: str, pretrained: bool = False, progress: bool = True, **kwargs: Any) -> VideoResNet:
+    if pretrained:
+        # the reference would download Kinetics weights here (resnet.py:287-289); its CLI can never
+        # request that and there is no network
+        raise RuntimeError(f"pretrained weights for {arch} are not available offline; load a checkpoint with "
+                           "load_state_dict instead")
+    return VideoResNet(**kwargs)
+
+
+def r3d_18(pretrained: bool = False, progress: bool = True, **kwargs: Any) -> VideoResNet:
+    """R3D-18: 3x3x3 convolutions throughout (resnet.py:293-314)."""
+    return _video_resnet("r3d_18", pretrained, progress, block=BasicBlock, conv_makers=[Conv3DSimple] * 4,
+                         layers=[2, 2, 2, 2], stem=BasicStem, **kwargs)
+
+
+def mc3_18(pretrained: bool = False, progress: bool = True, **kwargs: Any) -> VideoResNet:
+    """MC3-18: 3-D first stage, 2-D (1x3x3) afterwards (resnet.py:318-338)."""
+    return _video_resnet("mc3_18", pretrained, progress, block=BasicBlock,
+                         conv_makers=[Conv3DSimple] + [Conv3DNoTemporal] * 3, layers=[2, 2, 2, 2], stem=BasicStem,
+                         **kwargs)
+
+
+def r2plus1d_18(pretrained: bool = False, progress: bool = True, **kwargs: Any) -> VideoResNet:
+    """R(2+1)D-18: every 3-D convolution factorised into 1x3x3 + 3x1x1 (resnet.py:342-362)."""
+    return _video_resnet("r2plus1d_18", pretrained, progress, block=BasicBlock, conv_makers=[Conv2Plus1D] * 4,
+                         layers=[2, 2, 2, 2], stem=R2Plus1dStem, **kwargs)

@@ -1,0 +1,106 @@
+"""Training / evaluation step of the reference's driver, on the HIP path.
+
+``train_step`` reproduces the order of ``train_one_epoch`` (main.py:170-203): zero_grad ->
+forward -> MSE -> backward -> optimizer step, with ``main_02.py:256``'s handling of the
+``(emb, None)`` tuple.  The reference wraps forward in CUDA fp16 autocast +
+GradScaler (main.py:137,172,195-203); the fp32 configuration benchmarked here (BASELINE
+configs 1-3) runs without them, which is what the reference's CPU path does too (autocast is a
+no-op there).  The per-step train accuracy (main.py:182-185) is computed on the device so it
+does not stall the queue.
+
+``evaluate`` / ``compute_accuracy`` restate main.py:224-325: eval-mode forward under
+``no_grad``, cosine nearest class in the 300-d embedding space, top-1 / top-5, and the ten
+seeded half-class splits.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def embed(model: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    out = model(x)
+    return out[0] if isinstance(out, tuple) else out
+
+
+def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion, x: torch.Tensor,
+               z: torch.Tensor, grad_sync=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One iteration of main.py:170-203.  ``grad_sync`` (a ``ddp.GradientSync``) all-reduces the
+    gradients across ranks, overlapped with backward, before the optimizer step."""
+    optimizer.zero_grad(set_to_none=True)
+    if grad_sync is not None:
+        grad_sync.begin_step()
+    y = embed(model, x)
+    loss = criterion(y, z)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish_step()
+    optimizer.step()
+    return y.detach(), loss.detach()
+
+
+def cosine_ranking(pred: torch.Tensor, class_embed: torch.Tensor) -> torch.Tensor:
+    """argsort of scipy ``cdist(pred, class_embed, 'cosine')`` along classes (main.py:321)."""
+    sim = F.normalize(pred.float(), dim=1) @ F.normalize(class_embed.float(), dim=1).t()
+    return torch.argsort(1.0 - sim, dim=1, stable=True)
+
+
+def train_accuracy(y: torch.Tensor, class_embed: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """main.py:182-185 without leaving the device."""
+    pred = cosine_ranking(y, class_embed)[:, 0]
+    return (pred == labels.to(pred.device)).float().mean() * 100.0
+
+
+def compute_accuracy(predicted_embed: torch.Tensor, class_embed: torch.Tensor,
+                     true_embed: torch.Tensor) -> Tuple[float, float]:
+    """Top-1 / top-5 accuracy (percent) to the closest class embedding (main.py:316-325)."""
+    assert len(predicted_embed) == len(true_embed), "True and predicted labels must have the same number of samples"
+    order = cosine_ranking(predicted_embed, class_embed)
+    y = cosine_ranking(true_embed, class_embed)[:, 0]
+    top1 = (order[:, 0] == y).float().mean().item() * 100
+    top5 = (order[:, :5] == y[:, None]).any(dim=1).float().mean().item() * 100
+    return top1, top5
+
+
+@torch.no_grad()
+def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], class_embed: torch.Tensor,
+             device: Optional[torch.device] = None, splits: int = 10) -> dict:
+    """main.py:224-313 for one test set.  ``batches`` yields ``(X, labels, Z, ...)``; samples with
+    label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248."""
+    was_training = model.training
+    model.eval()
+    device = device or next(model.parameters()).device
+    preds, trues, labels = [], [], []
+    for batch in batches:
+        x, l, z = batch[0], batch[1], batch[2]
+        keep = l != -1
+        if keep.sum() == 0:
+            continue
+        x, l, z = x[keep], l[keep], z[keep]
+        preds.append(embed(model, x.to(device)).float())
+        trues.append(z.to(device).float().reshape(len(l), -1))
+        labels.append(l.reshape(-1))
+    model.train(was_training)
+    pred, true = torch.cat(preds), torch.cat(trues)
+    label = torch.cat(labels).cpu().numpy()
+    class_embed = class_embed.to(device)
+    acc, acc5 = compute_accuracy(pred, class_embed, true)
+    out = {"accuracy": acc, "accuracy_top5": acc5, "n": int(len(pred))}
+    if splits:
+        a1, a5 = [], []
+        for split in range(splits):
+            np.random.seed(split)                                     # main.py:284
+            sel_classes = np.random.permutation(len(class_embed))[:len(class_embed) // 2]
+            sel = torch.from_numpy(np.isin(label, sel_classes)).to(device)
+            if sel.sum() == 0:
+                continue
+            s1, s5 = compute_accuracy(pred[sel], class_embed[torch.from_numpy(sel_classes).to(device)], true[sel])
+            a1.append(s1)
+            a5.append(s5)
+        if a1:
+            out.update(split_accuracy=float(np.mean(a1)), split_accuracy_std=float(np.std(a1)),
+                       split_accuracy_top5=float(np.mean(a5)), split_accuracy_top5_std=float(np.std(a5)))
+    return out
