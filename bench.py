@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/sec of one full R(2+1)D-18 training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is main.py:170-203 of the reference: zero_grad -> forward -> MSE -> backward ->
+Adam, on 22 synthetic clips (3x16x112x112, fp32) per GPU with random-init weights
+(BASELINE.json configs[1]; per-GPU batch fixed => weak scaling); with N > 1 the gradients are
+averaged across ranks by the bucketed RCCL all-reduce of ``ddp.GradientSync``, overlapped
+with backward.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line.  Extra objects on that line:
+
+* ``roofline``  : the dominant kernel (the fp32-MFMA implicit-GEMM convolution on the
+  64->144 1x3x3 shape, 41 % of forward FLOPs): algorithmic FLOPs per launch / mean launch
+  duration from HIP events recorded on the launch stream inside the timed steps, against the
+  157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md);
+* ``cpu_baseline``: the CPU oracle (oracle/restatement.py, pinned to the reference) timed on
+  this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+T_START = time.perf_counter()
+CLIPS_PER_GPU = 22
+FRAMES, SIZE = 16, 112
+FP32_MFMA_PEAK_TFLOPS = 157.3
+# S1 of SURVEY section 2a: Conv3d(64, 144, (1,3,3), stride 1, pad (0,1,1)) on 16x56x56
+S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--network", default="r2plus1d_18")
+    ap.add_argument("--batch", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box
+    hands a 1-GPU job a share of a much larger host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, quota // int(f.read())))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("ZSV_CPU_THREADS", "64"))))
+
+
+def cpu_baseline(network: str, steps: int):
+    """Config A of BASELINE.md on the host cores: oracle train step, N = 2 clips."""
+    from oracle import restatement as R
+    from zeroshotvideoclassification_amd import synthetic
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
+    model = R.oracle_network(R.make_opt(network))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    n = 2
+    x = synthetic.synthetic_clips(n, FRAMES, SIZE)
+    _, z = synthetic.synthetic_targets(n)
+    R.train_step(model, opt, x, z)                       # warm-up (oneDNN primitive creation)
+    log("cpu_baseline: warm-up step done")
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        R.train_step(model, opt, x, z)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": n / med, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed train steps (median {med:.3f} s) of the CPU oracle on N=2 clips "
+                      f"3x{FRAMES}x{SIZE}x{SIZE} fp32 + Adam after 1 warm-up; oracle is pinned to the reference "
+                      "in the build container (tests/golden)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+
+    from zeroshotvideoclassification_amd import _lib, ddp, network, ops, synthetic, train
+    from types import SimpleNamespace
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(0)
+    model = network.get_network(SimpleNamespace(network=args.network, fixconvs=False, nopretrained=False))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
+    model.to(dev).train()
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    criterion = torch.nn.MSELoss().to(dev)
+    sync = ddp.GradientSync(model) if world > 1 else None
+
+    x = synthetic.synthetic_clips(args.batch, FRAMES, SIZE, rank=rank).to(dev)
+    _, z = synthetic.synthetic_targets(args.batch, rank=rank)
+    z = z.to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"model on {dev}, world {world}; warm-up {args.warmup} steps")
+    for i in range(args.warmup):
+        train.train_step(model, optimizer, criterion, x, z, sync)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    timer = ops.KernelTimer("conv_fwd", dict(S1_GEOMETRY, N=args.batch)) if args.network.startswith("r2plus1d") else None
+    ops.KERNEL_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    loss = None
+    for _ in range(args.steps):
+        _, loss = train.train_step(model, optimizer, criterion, x, z, sync)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        total_clips = world * args.batch * args.steps
+        value = total_clips / elapsed
+        out = {
+            "metric": "clips/sec (fwd+bwd+step) R(2+1)D-18 16x112x112 bs=22/GPU",
+            "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.network} training step (zero_grad+fwd+MSE+bwd+Adam), {args.batch} clips/GPU "
+                                   f"3x{FRAMES}x{SIZE}x{SIZE}, random-init, fp32 (BASELINE.json configs[1])",
+                       "clips_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}" + (" RCCL bucketed all-reduce overlapped with backward" if world > 1 else ""),
+                       "final_loss": float(loss.item()) if loss is not None else None},
+        }
+        # whole-step fractions of the two rooflines SURVEY section 8d defines
+        per_gpu = value / world
+        out["step_roofline"] = {"fp32_flop_frac": round(per_gpu * 242.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+                                "hbm_frac_unfused_bytes": round(per_gpu * 5.03e9 / 8.0e12, 4)}
+        if timer is not None and timer.pairs:
+            ms = timer.durations_ms()
+            mean_ms = sum(ms) / len(ms)
+            n = args.batch
+            flops = 2.0 * n * 144 * 64 * 9 * 16 * 56 * 56          # 8.324 GFLOP/clip
+            alg_bytes = 4.0 * (n * 64 * 16 * 56 * 56 + n * 144 * 16 * 56 * 56 + 144 * 64 * 9)
+            achieved = flops / (mean_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "conv_igemm_kernel<fwd> 64->144 1x3x3 @16x56x56 (4 launches/step)",
+                               "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
+                               "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
+                               "traffic": None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.network, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,7 +167,7 @@ class EmbeddingModel(nn.Module):
         self.feature2input_proj = nn.Linear(512, 256)
         layer = nn.TransformerEncoderLayer(d_model=256, dim_feedforward=1024, nhead=8,
                                            dropout=0.1, activation="gelu")
-        self.encoder = nn.TransformerEncoder(layer, num_layers=6)
+        self.encoder = nn.TransformerEncoder(layer, num_layers=6, enable_nested_tensor=False)
         self.output2emb_proj = MLPHead(512, 512, 300, 2)
         nn.init.normal_(self.t_pos_embeds.weight)
         nn.init.xavier_uniform_(self.special_tokens.weight)

@@ -1,0 +1,175 @@
+"""End-to-end parity of the HIP model path against the reference-generated golden vectors.
+
+north_star tolerance: embeddings and MSE loss within 1e-3 relative (fp32).  Tighter bounds
+are asserted where the fp32-vs-fp64 noise floor allows: 1e-4 on embeddings
+/ loss / BatchNorm statistics, gradient norms per parameter within 3e-2 of the fp64 oracle
+(BN-backward cancellation puts fp32 CPU itself 1e-2 away from fp64).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import case_inputs, load_golden, make_opt, rel_err, rel_l2, sample_idx  # noqa: E402
+from zeroshotvideoclassification_amd import network, synthetic, train  # noqa: E402
+
+DEV = "cuda"
+EMB_TOL = 1e-3          # north_star bar
+TIGHT = 1e-4
+
+
+def build(case):
+    g = load_golden(case)
+    model = network.get_network(make_opt(str(g["meta_network"])))
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=bool(g["meta_bn_jitter"]))
+    model.load_state_dict(weights)
+    return g, model.to(DEV), weights
+
+
+@pytest.mark.parametrize("case", ["r2plus1d_small", "r3d_small", "r2plus1d_jitter", "r2plus1d_A"])
+def test_train_mode_forward_backward(case):
+    g, model, _ = build(case)
+    x, z = case_inputs(g)
+    model.train()
+    bn_in = {}
+    hooks = []
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            hooks.append(m.register_forward_hook(
+                lambda mod, inp, out, name=name: bn_in.__setitem__(name, inp[0].detach())))
+    y = train.embed(model, x.to(DEV))
+    loss = F.mse_loss(y, z.to(DEV))
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    torch.cuda.synchronize()
+
+    ynp = y.detach().cpu().numpy()
+    assert rel_err(ynp, g["emb_f32"]) < EMB_TOL      # the stated bar
+    assert rel_err(ynp, g["emb_f32"]) < TIGHT
+    assert rel_err(ynp, g["emb_f64"]) < TIGHT
+    assert abs(loss.item() - float(g["loss_f32"])) / float(g["loss_f32"]) < TIGHT
+
+    # BatchNorm batch statistics of every BN input (the golden file lists them in the reference's
+    # call order; the fused block runs the shortcut BN before conv2's BN, so compare by name)
+    names = [str(n) for n in g["bn_names"]]
+    assert sorted(bn_in.keys()) == sorted(names)
+    mean = torch.cat([bn_in[n].double().mean(dim=(0, 2, 3, 4)) for n in names]).cpu().numpy()
+    var = torch.cat([bn_in[n].double().var(dim=(0, 2, 3, 4), unbiased=False) for n in names]).cpu().numpy()
+    assert np.abs(mean - g["bn_mean"]).max() < 1e-4 * (np.abs(g["bn_mean"]).max() + np.sqrt(g["bn_var"].max()))
+    assert rel_err(var, g["bn_var"]) < 1e-4
+
+    # which parameters receive gradients (dead Transformer encoder etc. must stay None)
+    live = [k for k, p in model.named_parameters() if p.grad is not None]
+    dead = [k for k, p in model.named_parameters() if p.grad is None]
+    assert live == [str(k) for k in g["live_params"]]
+    assert dead == [str(k) for k in g["dead_params"]]
+
+    # per-parameter gradient norms + samples vs the fp64 oracle
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for name, norm, sample in zip(g["grad_names"], g["grad_norm_f64"], g["grad_sample_f64"]):
+        gr = params[str(name)].grad.double().flatten()
+        worst = max(worst, abs(gr.norm().item() - norm) / (norm + 1e-30))
+        idx = sample_idx(gr.numel(), 16)
+        got = gr[torch.from_numpy(idx).to(gr.device)].cpu().numpy()
+        # individual tiny-gradient elements carry the fp32 BN-backward cancellation noise (SURVEY
+        # section 4: fp32 CPU vs fp64 CPU is already ~1e-2 rel-L2), so compare the sample vector in L2
+        assert rel_l2(got, sample[:len(idx)]) < 0.1, str(name)
+    assert worst < 3e-2, f"worst grad-norm deviation {worst:.3e}"
+
+
+@pytest.mark.parametrize("case", ["r2plus1d_small", "r2plus1d_jitter"])
+def test_stage_statistics(case):
+    g, model, _ = build(case)
+    x, _ = case_inputs(g)
+    model.train()
+    trunk = model.model
+    with torch.no_grad():
+        t = x.reshape(x.shape[0], *x.shape[2:]).to(DEV)
+        feats = [trunk.stem(t)]
+        for i in range(1, 5):
+            feats.append(getattr(trunk, f"layer{i}")(feats[-1]))
+    for name, f in zip(["stem", "layer1", "layer2", "layer3", "layer4"], feats):
+        flat = f.flatten()
+        assert abs(flat.double().mean().item() - float(g[f"stage_{name}_mean"])) < 1e-4 * float(g[f"stage_{name}_absmean"])
+        assert abs(flat.double().abs().mean().item() / float(g[f"stage_{name}_absmean"]) - 1) < 1e-4
+        idx = torch.from_numpy(sample_idx(flat.numel())).to(DEV)
+        assert rel_err(flat[idx].cpu().numpy(), g[f"stage_{name}_sample"]) < 5e-4, name
+
+
+@pytest.mark.parametrize("case", ["r2plus1d_small", "r2plus1d_jitter"])
+def test_adam_steps_running_stats_and_eval(case):
+    g, model, weights = build(case)
+    x, z = case_inputs(g)
+    xd, zd = x.to(DEV), z.to(DEV)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    _, l1 = train.train_step(model, opt, crit, xd, zd)
+    sd = model.state_dict()
+    rm = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_mean")]).cpu().numpy()
+    rv = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_var")]).cpu().numpy()
+    assert abs(l1.item() / float(g["step1_loss"]) - 1) < TIGHT
+    assert np.abs(rm - g["running_mean_after1"]).max() < 1e-4 * (np.abs(g["running_mean_after1"]).max() + 1)
+    assert rel_err(rv, g["running_var_after1"]) < 1e-4
+    nbt = [int(sd[k]) for k in sd if k.endswith("num_batches_tracked")]
+    assert set(nbt) == {1}
+    # second step: Adam's first update is ~lr*sign(g), so sign flips of tiny grads move the loss;
+    # sanity only
+    _, l2 = train.train_step(model, opt, crit, xd, zd)
+    assert abs(l2.item() / float(g["step2_loss"]) - 1) < 0.2
+
+    model.load_state_dict(weights)
+    model.eval()
+    with torch.no_grad():
+        ye = train.embed(model, xd)
+    assert rel_err(ye.cpu().numpy(), g["emb_eval_f32"]) < TIGHT
+    if "emb_eval_t32_f32" in g:          # config E geometry: 32-frame clip through eval-mode BN
+        x32 = synthetic.synthetic_clips(1, 32, int(g["meta_size"]), seed=99)
+        with torch.no_grad():
+            y32 = train.embed(model, x32.to(DEV))
+        assert rel_err(y32.cpu().numpy(), g["emb_eval_t32_f32"]) < TIGHT
+
+
+def test_c3d_eval_forward_backward():
+    g, model, _ = build("c3d_eval")
+    x, z = case_inputs(g)
+    model.eval()                                   # dropout off
+    y = train.embed(model, x.to(DEV))
+    loss = F.mse_loss(y, z.to(DEV))
+    loss.backward()
+    assert rel_err(y.detach().cpu().numpy(), g["emb_f32"]) < TIGHT
+    assert abs(loss.item() / float(g["loss_f32"]) - 1) < TIGHT
+    params = dict(model.named_parameters())
+    for name, norm in zip(g["grad_names"], g["grad_norm_f64"]):
+        gr = params[str(name)].grad
+        assert gr is not None, name
+        assert abs(gr.double().norm().item() - norm) <= 2e-3 * norm + 1e-12, str(name)
+    assert [k for k, p in model.named_parameters() if p.grad is None] == [str(k) for k in g["dead_params"]]
+
+
+def test_fixconvs_freezes_trunk_and_skips_its_gradients():
+    model = network.get_network(make_opt("r2plus1d_18", fixconvs=True)).to(DEV)
+    x = synthetic.synthetic_clips(1, 4, 32).to(DEV)
+    y, _ = model(x)
+    y.sum().backward()
+    assert all(p.grad is None for p in model.model.parameters())
+    assert all(p.grad is not None for p in model.output2emb_proj.parameters())
+
+
+def test_evaluate_protocol_on_gpu():
+    g, model, _ = build("r2plus1d_small")
+    classes = synthetic.class_table(51, seed=77)
+    batches = []
+    for i in range(3):
+        x = synthetic.synthetic_clips(2, 8, 56, seed=500 + i)
+        labels, z = synthetic.synthetic_targets(2, 51, seed=77, rank=i)
+        if i == 1:
+            labels[0] = -1                                     # broken sample is dropped (main.py:246)
+        batches.append((x, labels, z, torch.arange(2)))
+    res = train.evaluate(model, batches, classes)
+    assert res["n"] == 5
+    assert 0.0 <= res["accuracy"] <= res["accuracy_top5"] <= 100.0

@@ -81,7 +81,7 @@ class Model(nn.Module):
         self.encoder = nn.TransformerEncoder(
             nn.TransformerEncoderLayer(d_model=self.d_model, dim_feedforward=self.d_model * 4, nhead=8, dropout=0.1,
                                        activation="gelu"),
-            num_layers=6)
+            num_layers=6, enable_nested_tensor=False)
         self.output2emb_proj = MLP(512, 512, 300, 2)
         self.reset_parameters()
 

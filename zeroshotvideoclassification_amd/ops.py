@@ -57,6 +57,37 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
 
+class KernelTimer:
+    """Optional HIP-event timing of one kernel family on one geometry (used by bench.py for the
+    live roofline figure): events are recorded on the launch stream around matching launches;
+    nothing synchronises until ``durations_ms()`` is read."""
+
+    def __init__(self, kind: str, geometry: dict):
+        self.kind = kind
+        self.geometry = dict(geometry)
+        self.pairs = []
+
+    def wants(self, kind: str, d: ConvDesc) -> bool:
+        return kind == self.kind and all(getattr(d, k) == v for k, v in self.geometry.items())
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def stop(self, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream())
+        self.pairs.append((e0, e1))
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+
+
 def conv_desc(x_shape: Sequence[int], w_shape: Sequence[int], stride, padding) -> ConvDesc:
     n, cin, ti, hi, wi = (int(v) for v in x_shape)
     cout, cin_w, kt, kh, kw = (int(v) for v in w_shape)
@@ -87,9 +118,13 @@ class _Conv3d(Function):
         d = conv_desc(x.shape, weight.shape, stride, padding)
         y = torch.empty((d.N, d.Cout, d.To, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
         lib = _lib.load()
+        timer = KERNEL_TIMER
         with torch.cuda.device(x.device):
+            ev = timer.start() if (timer is not None and timer.wants("conv_fwd", d)) else None
             _lib.check(lib.zsv_conv3d_fwd(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
                                           1 if relu else 0, _stream()), "zsv_conv3d_fwd")
+            if ev is not None:
+                timer.stop(ev)
         ctx.desc = d
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
