@@ -5,30 +5,37 @@
 //
 // Design (MI355X-first, not a port of anything):
 //   * Implicit GEMM  C[m][p] = sum_k A[m][k] * B[k][p]  with the channel being produced on
-//     the MFMA row axis and output voxels p = (n, t, h, w) on the column axis, so a
-//     16-lane group of the accumulator maps to 16 consecutive voxels (64-B store
-//     segments along W, the contiguous NCDHW axis).
-//   * The contraction runs on the fp32-input matrix core, v_mfma_f32_16x16x4_f32: it is
-//     bit-exact fp32 (one rounding per product, an fmaf chain in k order) and issues at
-//     the same 64 FLOP/clk/SIMD as the fp32 vector pipe, but needs one VGPR per operand
-//     and leaves the VALU free for the gather address arithmetic.
+//     the MFMA row axis and voxels p = (n, t, h, w) on the column axis, so a 16-lane group
+//     of the accumulator maps to 16 consecutive voxels (64-B store segments along W, the
+//     contiguous NCDHW axis).
+//   * The contraction runs on the fp32-input matrix core, v_mfma_f32_16x16x4_f32: bit-exact
+//     fp32 (one rounding per product, an fmaf chain in k order) at the fp32 vector rate, one
+//     VGPR per operand, VALU left free for the gather arithmetic.
 //   * B is never materialised in HBM: each K-chunk's (BK x BN) im2col slab is gathered
-//     straight from the NCDHW tensor into LDS.  A wave owns whole k-rows of the slab, so
-//     (channel, tap) decoding is per row (done once per chunk by BK lanes, broadcast
-//     through LDS) and each lane only adds a row offset to its voxel's base offset and
-//     tests three bits of a per-voxel padding mask.  Lanes walk W, so the global loads
-//     are coalesced along W as far as stride allows.
-//   * Register-staged double buffering: global loads for chunk i+1 are issued before the
-//     MFMAs of chunk i and written to the other LDS buffer afterwards; one barrier per
-//     chunk.
-//   * The same kernel computes dgrad: rows are input channels, columns are input voxels,
-//     and the gather reads dy at (t + pT - kt)/sT when divisible (per-voxel masks hold the
-//     divisibility + range test per tap index), weights are addressed transposed.
+//     straight from the NCDHW tensor into LDS.  A wave owns whole k-rows of the slab, so the
+//     (channel, tap) decode is per row: BK lanes decode a chunk's rows one chunk ahead and
+//     publish {byte offset, tap} through LDS; consumers pull them into SGPRs
+//     (v_readfirstlane).  Per element a lane does: bit-extract its voxel's tap-validity
+//     mask, add the row offset, OR in the out-of-range flag -- 4 VALU -- and issues a
+//     `buffer_load_dword`: the buffer descriptor's range check returns 0 for padded taps, so
+//     there is no branch and no select behind the load.  Lanes walk W: loads coalesce.
+//   * Register-staged double buffering: loads for chunk i+1 are issued first, then all MFMA
+//     fragments of chunk i are fetched from LDS in one burst, then the chunk's MFMAs run
+//     back to back; the staged registers are written to the other LDS buffer afterwards
+//     (that is where the vmcnt wait lands); one barrier per chunk.
+//   * dgrad runs on the same kernel: it is a correlation of dy with the transposed kernel.
+//     A strided convolution's dgrad is split into sT*sH*sW residue classes of input voxels;
+//     each class is a dense stride-1 problem over its own taps (no multiplies by the zeros
+//     a naive "insert zeros" transposed convolution would do: 4x fewer MFMAs for the 1x3x3
+//     stride-2 layers, 8x for the 1x1x1 shortcuts).
+//   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each walk a contiguous range of
+//     tiles, so tiles that share gathered input rows and the weight panel share an L2.
 //
 // LDS images: As[BK][LDA], Bs[BK][LDB] with LD == 16 (mod 32) so that the two k-rows a
 // 32-lane group touches in one ds_read_b32 fall on disjoint bank halves.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "zsv_hip.h"
 #include "zsv_common.h"
 
@@ -36,27 +43,35 @@ namespace zsv {
 
 struct IgemmParams {
     int M;          // rows: channels produced (Cout fwd / Cin dgrad)
-    int P;          // columns: N * oS voxels of the produced tensor
+    int P;          // columns: voxels of this launch (N * class grid)
     int K;          // reduction: Cred * taps
-    int taps;       // kT*kH*kW
-    int kHW, kW;    // for tap -> (kt, kh, kw)
-    int oS, oHW, oW;    // produced tensor: voxels per clip, H*W, W
-    int gC;             // channels of the gathered tensor
-    int gT, gH, gW;     // gathered tensor spatial dims
-    int gS, gHW;        // gathered tensor: voxels per channel, H*W
-    int sT, sH, sW;
-    int pT, pH, pW;
-    int kT, kH;
-    int a_col_stride;   // A(m, k) = a[m * a_col_stride + a_rowoff(k)]
+    // taps of this launch (the whole kernel for fwd, one residue class for dgrad)
+    int taps, nHW, nW, nT, nH;
+    // column decode over the class grid (cT, cH, cW)
+    int cS, cHW, cW;
+    // produced tensor (full) and where class voxel (ct, ch, cw) lands in it
+    int oS, oHW, oW;
+    int stT, stH, stW, rT, rH, rW;
+    // gathered tensor and the gather rule: coord = c * gs + go + dir * j, valid in [0, g)
+    int gC, gT, gH, gW, gS, gHW;
+    int gsT, gsH, gsW, goT, goH, goW;
+    int dir;
+    // weights: A(m, k = (c, tap)) = a[m * a_m_stride + c * a_c_stride + tap_full]
+    //   tap_full = ((k0T + tsT*jt) * kH + k0H + tsH*jh) * kW + k0W + tsW*jw
+    int a_m_stride, a_c_stride;
+    int k0T, k0H, k0W, tsT, tsH, tsW, kH, kW;
+    unsigned g_bytes, a_bytes;     // buffer sizes for the hardware range check
     int relu;
 };
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
 
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // ---------------------------------------------------------------------------------
-template <int TM, int TN, int WGM, int WGN, int MODE, bool AVEC>
+// AVEC: A rows are contiguous in k and 16-B aligned (forward, K % 4 == 0): float4 staging.
+// WIDE: more than 31 taps (7x7 stems): per-axis validity masks instead of one tap mask.
+template <int TM, int TN, int WGM, int WGN, bool AVEC, bool WIDE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
                                                          const float* __restrict__ A,
                                                          const float* __restrict__ G,
@@ -74,79 +89,82 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
     constexpr int BPASS = BK / BROWS;           // passes per chunk
     constexpr int APASS = (BM * BK + NT - 1) / NT;          // scalar A staging
     constexpr int AVPASS = (BM * (BK / 4) + NT - 1) / NT;   // float4 A staging
+    constexpr unsigned OOB = 0xFFFFFFFFu;
 
     __shared__ float As[2][BK * LDA];
     __shared__ float Bs[2][BK * LDB];
-    __shared__ int rinfo[2][BK][4];   // {gather offset, packed shifts, A row offset, -}
+    __shared__ int rinfo[2][BK][4];   // {gather byte offset, tap | packed shifts, A offset, -}
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = sgpr(tid >> 6);
     const int wm0 = (wave / WGN) * (16 * TM);
     const int wn0 = (wave % WGN) * (16 * TN);
 
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous range
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int m0 = (tile % tiles_m) * BM;
     const int n0 = (tile / tiles_m) * BN;
 
-    // ---- per-thread gather column: voxel -> base offset + padding mask -------------
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, prm.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, prm.a_bytes, 0x00020000);
+
+    // ---- per-thread gather column: voxel -> base byte offset + tap-validity mask ----------
     const int bcol = tid % BN;
-    const int brow0 = __builtin_amdgcn_readfirstlane(tid / BN);
-    int base_off = 0;
-    unsigned vmask = 0;
+    const int brow0 = sgpr(tid / BN);
+    int base_bytes = 0;
+    unsigned vmask = 0;          // !WIDE: bit tap = tap valid;  WIDE: w bits 0-6, h 8-14, t 16-22
     {
         const int p = n0 + bcol;
         if (p < prm.P) {
-            const int n = p / prm.oS;
-            int r = p - n * prm.oS;
-            const int ot = r / prm.oHW;
-            r -= ot * prm.oHW;
-            const int oh = r / prm.oW;
-            const int ow = r - oh * prm.oW;
-            if (MODE == MODE_FWD) {
-                const int t0 = ot * prm.sT - prm.pT, h0 = oh * prm.sH - prm.pH, w0 = ow * prm.sW - prm.pW;
-                base_off = n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0;
-                for (int k = 0; k < prm.kW; ++k) vmask |= ((unsigned)(w0 + k) < (unsigned)prm.gW) << k;
-                for (int k = 0; k < prm.kH; ++k) vmask |= ((unsigned)(h0 + k) < (unsigned)prm.gH) << (8 + k);
-                for (int k = 0; k < prm.kT; ++k) vmask |= ((unsigned)(t0 + k) < (unsigned)prm.gT) << (16 + k);
+            const int n = p / prm.cS;
+            int r = p - n * prm.cS;
+            const int ct = r / prm.cHW;
+            r -= ct * prm.cHW;
+            const int ch = r / prm.cW;
+            const int cw = r - ch * prm.cW;
+            const int t0 = ct * prm.gsT + prm.goT, h0 = ch * prm.gsH + prm.goH, w0 = cw * prm.gsW + prm.goW;
+            base_bytes = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
+            unsigned mw = 0, mh = 0, mt = 0;
+            for (int j = 0; j < prm.nW; ++j) mw |= ((unsigned)(w0 + prm.dir * j) < (unsigned)prm.gW) << j;
+            for (int j = 0; j < prm.nH; ++j) mh |= ((unsigned)(h0 + prm.dir * j) < (unsigned)prm.gH) << j;
+            for (int j = 0; j < prm.nT; ++j) mt |= ((unsigned)(t0 + prm.dir * j) < (unsigned)prm.gT) << j;
+            if (WIDE) {
+                vmask = mw | (mh << 8) | (mt << 16);
             } else {
-                const int tb = ot + prm.pT, hb = oh + prm.pH, wb = ow + prm.pW;
-                const int tq = tb / prm.sT, hq = hb / prm.sH, wq = wb / prm.sW;
-                const int tr = tb - tq * prm.sT, hr = hb - hq * prm.sH, wr = wb - wq * prm.sW;
-                base_off = n * prm.gC * prm.gS + tq * prm.gHW + hq * prm.gW + wq;
-                for (int k = 0; k < prm.kW; ++k)
-                    vmask |= ((k % prm.sW == wr) && (unsigned)(wq - k / prm.sW) < (unsigned)prm.gW) << k;
-                for (int k = 0; k < prm.kH; ++k)
-                    vmask |= ((k % prm.sH == hr) && (unsigned)(hq - k / prm.sH) < (unsigned)prm.gH) << (8 + k);
-                for (int k = 0; k < prm.kT; ++k)
-                    vmask |= ((k % prm.sT == tr) && (unsigned)(tq - k / prm.sT) < (unsigned)prm.gT) << (16 + k);
+                int tap = 0;
+                for (int a = 0; a < prm.nT; ++a)
+                    for (int b = 0; b < prm.nH; ++b)
+                        for (int c = 0; c < prm.nW; ++c, ++tap)
+                            vmask |= (((mt >> a) & (mh >> b) & (mw >> c)) & 1u) << tap;
             }
         }
     }
 
-    // ---- row decode: k -> gather offset / mask shifts / A offset (BK lanes per chunk) --
+    // ---- row decode: k -> gather offset / tap / A offset (BK lanes, one chunk ahead) ------
     auto decode_rows = [&](int k0, int buf) {
         if (tid < BK) {
             const int k = k0 + tid;
-            int goff = 0, shifts = 31 | (31 << 8) | (31 << 16), aoff = -1;
+            int goff = 0, sel = WIDE ? (31 | (31 << 8) | (31 << 16)) : 31, aoff = -1;
             if (k < prm.K) {
                 const int c = k / prm.taps;
                 const int tap = k - c * prm.taps;
-                const int kt = tap / prm.kHW;
-                const int r = tap - kt * prm.kHW;
-                const int kh = r / prm.kW;
-                const int kw = r - kh * prm.kW;
-                shifts = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
-                if (MODE == MODE_FWD) {
-                    goff = c * prm.gS + kt * prm.gHW + kh * prm.gW + kw;
-                    aoff = k;
-                } else {
-                    goff = c * prm.gS - (kt / prm.sT) * prm.gHW - (kh / prm.sH) * prm.gW - (kw / prm.sW);
-                    aoff = c * (prm.M * prm.taps) + tap;
-                }
+                const int jt = tap / prm.nHW;
+                const int r = tap - jt * prm.nHW;
+                const int jh = r / prm.nW;
+                const int jw = r - jh * prm.nW;
+                sel = WIDE ? (jw | ((8 + jh) << 8) | ((16 + jt) << 16)) : tap;
+                goff = 4 * (c * prm.gS + prm.dir * (jt * prm.gHW + jh * prm.gW + jw));
+                aoff = c * prm.a_c_stride +
+                       ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
             }
             rinfo[buf][tid][0] = goff;
-            rinfo[buf][tid][1] = shifts;
+            rinfo[buf][tid][1] = sel;
             rinfo[buf][tid][2] = aoff;
         }
     };
@@ -159,42 +177,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
             const int row = brow0 + BROWS * j;
-            const int goff = rinfo[buf][row][0];
-            const int sh = rinfo[buf][row][1];
-            const unsigned ok = (vmask >> (sh & 31)) & (vmask >> ((sh >> 8) & 31)) & (vmask >> ((sh >> 16) & 31)) & 1u;
-            const int off = ok ? base_off + goff : 0;
-            const float v = G[off];
-            breg[j] = ok ? v : 0.f;
+            const int goff = sgpr(rinfo[buf][row][0]);
+            const int sel = sgpr(rinfo[buf][row][1]);
+            unsigned ok;
+            if (WIDE)
+                ok = (vmask >> (sel & 31)) & (vmask >> ((sel >> 8) & 31)) & (vmask >> ((sel >> 16) & 31)) & 1u;
+            else
+                ok = (vmask >> sel) & 1u;
+            const unsigned off = (unsigned)(base_bytes + goff) | (ok - 1u);     // invalid -> 0xFFFFFFFF (range check -> 0)
+            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)off, 0, 0));
         }
         if (AVEC) {
 #pragma unroll
             for (int j = 0; j < AVPASS; ++j) {
                 const int e = tid + NT * j;
                 const int m = e % BM, kq = e / BM;
+                // (hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a one-dword load, so the
+                // 16-B weight loads stay plain global loads from a clamped address; rows m >= M are
+                // never stored and k >= K is zeroed when the registers are written to LDS)
                 const bool ok = (e < BM * (BK / 4)) && (m0 + m < prm.M) && (k0 + 4 * kq < prm.K);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v = *reinterpret_cast<const float4*>(A + (size_t)(m0 + m) * prm.K + k0 + 4 * kq);
+                const size_t off = ok ? (size_t)(m0 + m) * prm.a_m_stride + k0 + 4 * kq : 0;
+                const float4 v = *reinterpret_cast<const float4*>(A + off);
                 areg[4 * j + 0] = v.x; areg[4 * j + 1] = v.y; areg[4 * j + 2] = v.z; areg[4 * j + 3] = v.w;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
                 const int e = tid + NT * j;
-                const int row = e / BM, m = e % BM;
-                float v = 0.f;
-                if (e < BM * BK) {
-                    const int aoff = rinfo[buf][row][2];
-                    const bool ok = (m0 + m < prm.M) && (aoff >= 0);
-                    const int off = ok ? (m0 + m) * prm.a_col_stride + aoff : 0;
-                    v = A[off];
-                    v = ok ? v : 0.f;
-                }
-                areg[j] = v;
+                const int row = (e / BM) % BK, m = e % BM;
+                const int aoff = rinfo[buf][row][2];
+                const bool ok = (e < BM * BK) && (m0 + m < prm.M) && (aoff >= 0);
+                const unsigned off = ok ? 4u * (unsigned)((m0 + m) * prm.a_m_stride + aoff) : OOB;
+                areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, (int)off, 0, 0));
             }
         }
     };
 
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int knext) {
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) Bs[buf][(brow0 + BROWS * j) * LDB + bcol] = breg[j];
         if (AVEC) {
@@ -203,8 +222,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
                 const int e = tid + NT * j;
                 const int m = e % BM, kq = e / BM;
                 if (e < BM * (BK / 4)) {
+                    const bool kvalid = (knext + 4 * kq) < prm.K;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) As[buf][(4 * kq + r) * LDA + m] = areg[4 * j + r];
+                    for (int r = 0; r < 4; ++r) As[buf][(4 * kq + r) * LDA + m] = kvalid ? areg[4 * j + r] : 0.f;
                 }
             }
         } else {
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
     __syncthreads();
     load_chunk(0, 0);
     decode_rows(BK, 1);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
 
     const int frag_row = lane >> 4;      // k within a 4-deep MFMA step
@@ -238,29 +258,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
         const bool more = (ch + 1) < nchunks;
-        if (more) {
-            load_chunk((ch + 1) * BK, cur ^ 1);      // uses rinfo[cur^1] (decoded last iteration)
-        }
+        if (more) load_chunk((ch + 1) * BK, cur ^ 1);      // rinfo[cur^1] was decoded last iteration
         // rinfo[cur] was consumed by the loads issued in the previous iteration
-        // (and nobody reads it again before the barrier below)
         if (ch + 2 < nchunks) decode_rows((ch + 2) * BK, cur);
 
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
+        float a[BK / 4][TM], b[BK / 4][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(kk * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
+            for (int i = 0; i < TM; ++i) a[kk][i] = as[(kk * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(kk * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+            for (int j = 0; j < TN; ++j) b[kk][j] = bs[(kk * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+        }
+        // keep the whole fragment burst ahead of the MFMA chain (hipcc otherwise sinks each
+        // ds_read next to its first use and waits lgkmcnt(0) every 4 MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_chunk(cur ^ 1);
+        if (more) store_chunk(cur ^ 1, (ch + 1) * BK);
         __syncthreads();
     }
 
@@ -269,16 +292,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
     for (int j = 0; j < TN; ++j) {
         const int p = n0 + wn0 + 16 * j + frag_col;
         if (p >= prm.P) continue;
-        const int n = p / prm.oS;
-        const int sp = p - n * prm.oS;
+        const int n = p / prm.cS;
+        int r = p - n * prm.cS;
+        const int ct = r / prm.cHW;
+        r -= ct * prm.cHW;
+        const int chh = r / prm.cW;
+        const int cw = r - chh * prm.cW;
+        const int sp = (ct * prm.stT + prm.rT) * prm.oHW + (chh * prm.stH + prm.rH) * prm.oW + cw * prm.stW + prm.rW;
         float* cbase = C + (size_t)n * prm.M * prm.oS + sp;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm0 + 16 * i + 4 * frag_row + r;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int m = m0 + wm0 + 16 * i + 4 * frag_row + r4;
                 if (m < prm.M) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r4];
                     if (bias != nullptr) v += bias[m];
                     if (prm.relu) v = fmaxf(v, 0.f);
                     cbase[(size_t)m * prm.oS] = v;
@@ -289,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
 }
 
 // ---------------------------------------------------------------------------------
-template <int TM, int TN, int WGM, int WGN, int MODE, bool AVEC>
+template <int TM, int TN, int WGM, int WGN, bool AVEC, bool WIDE>
 static int launch_cfg(const IgemmParams& prm, const float* A, const float* G, const float* bias,
                       float* C, hipStream_t stream) {
     constexpr int BM = 16 * TM * WGM;
@@ -298,7 +326,7 @@ static int launch_cfg(const IgemmParams& prm, const float* A, const float* G, co
     const long tiles_n = ((long)prm.P + BN - 1) / BN;
     const long blocks = tiles_m * tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
-    hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WGM, WGN, MODE, AVEC>), dim3((unsigned)blocks),
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, WGM, WGN, AVEC, WIDE>), dim3((unsigned)blocks),
                        dim3(256), 0, stream, prm, A, G, bias, C, tiles_m);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
@@ -309,7 +337,7 @@ static inline double padded_work(int M, long P, int BM, int BN) {
     return tm * BM * tn * BN;
 }
 
-template <int MODE, bool AVEC>
+template <bool AVEC, bool WIDE>
 static int dispatch(const IgemmParams& prm, const float* A, const float* G, const float* bias,
                     float* C, hipStream_t stream) {
     // candidate row tilings (BM): 48, 64, 80, 128, 144; pick the least padded work,
@@ -325,13 +353,25 @@ static int dispatch(const IgemmParams& prm, const float* A, const float* G, cons
         if (blocks < 512) w *= (512.0 / (blocks < 1 ? 1 : blocks)) > 4.0 ? 4.0 : (512.0 / blocks);
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
+    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e);     // tuning override (tools/conv_bench.py)
     switch (best) {
-        case 0: return launch_cfg<9, 2, 1, 4, MODE, AVEC>(prm, A, G, bias, C, stream);
-        case 1: return launch_cfg<4, 4, 2, 2, MODE, AVEC>(prm, A, G, bias, C, stream);
-        case 2: return launch_cfg<5, 2, 1, 4, MODE, AVEC>(prm, A, G, bias, C, stream);
-        case 3: return launch_cfg<4, 2, 1, 4, MODE, AVEC>(prm, A, G, bias, C, stream);
-        default: return launch_cfg<3, 4, 1, 4, MODE, AVEC>(prm, A, G, bias, C, stream);
+        case 0: return launch_cfg<9, 2, 1, 4, AVEC, WIDE>(prm, A, G, bias, C, stream);
+        case 1: return launch_cfg<4, 4, 2, 2, AVEC, WIDE>(prm, A, G, bias, C, stream);
+        case 2: return launch_cfg<5, 2, 1, 4, AVEC, WIDE>(prm, A, G, bias, C, stream);
+        case 3: return launch_cfg<4, 2, 1, 4, AVEC, WIDE>(prm, A, G, bias, C, stream);
+        default: return launch_cfg<3, 4, 1, 4, AVEC, WIDE>(prm, A, G, bias, C, stream);
     }
+}
+
+static int dispatch_any(const IgemmParams& prm, bool avec, const float* A, const float* G, const float* bias,
+                        float* C, hipStream_t stream) {
+    const bool wide = prm.taps > 31;
+    if (wide) {
+        // the 7x7 stems: never vectorised A (K = 147 / 441)
+        return dispatch<false, true>(prm, A, G, bias, C, stream);
+    }
+    if (avec) return dispatch<true, false>(prm, A, G, bias, C, stream);
+    return dispatch<false, false>(prm, A, G, bias, C, stream);
 }
 
 int conv_check(const zsv_conv_desc* d) {
@@ -343,23 +383,13 @@ int conv_check(const zsv_conv_desc* d) {
     if (d->Ho != (d->Hi + 2 * d->pH - d->kH) / d->sH + 1) return ZSV_E_BAD_SHAPE;
     if (d->Wo != (d->Wi + 2 * d->pW - d->kW) / d->sW + 1) return ZSV_E_BAD_SHAPE;
     if (d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return ZSV_E_BAD_SHAPE;
-    const double lim = 2147483647.0;
+    // byte offsets are 32-bit (buffer addressing): every tensor must stay below 2^30 elements
+    const double lim = 1073741823.0;
     const double xin = (double)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
     const double yout = (double)d->N * d->Cout * d->To * d->Ho * d->Wo;
     const double wn = (double)d->Cout * d->Cin * d->kT * d->kH * d->kW;
     if (xin >= lim || yout >= lim || wn >= lim) return ZSV_E_TOO_LARGE;
     return ZSV_OK;
-}
-
-static void fill_common(IgemmParams& p, const zsv_conv_desc* d) {
-    p.taps = d->kT * d->kH * d->kW;
-    p.kHW = d->kH * d->kW;
-    p.kW = d->kW;
-    p.kH = d->kH;
-    p.kT = d->kT;
-    p.sT = d->sT; p.sH = d->sH; p.sW = d->sW;
-    p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
-    p.relu = 0;
 }
 
 }  // namespace zsv
@@ -371,19 +401,26 @@ extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const floa
     int st = conv_check(d);
     if (st) return st;
     if (!x || !w || !y) return ZSV_E_NULL;
-    IgemmParams p;
-    fill_common(p, d);
+    IgemmParams p = {};
+    const int taps = d->kT * d->kH * d->kW;
     p.M = d->Cout;
     p.P = d->N * d->To * d->Ho * d->Wo;
-    p.K = d->Cin * p.taps;
-    p.oS = d->To * d->Ho * d->Wo; p.oHW = d->Ho * d->Wo; p.oW = d->Wo;
+    p.K = d->Cin * taps;
+    p.taps = taps; p.nHW = d->kH * d->kW; p.nW = d->kW; p.nT = d->kT; p.nH = d->kH;
+    p.cS = d->To * d->Ho * d->Wo; p.cHW = d->Ho * d->Wo; p.cW = d->Wo;
+    p.oS = p.cS; p.oHW = p.cHW; p.oW = p.cW;
+    p.stT = p.stH = p.stW = 1; p.rT = p.rH = p.rW = 0;
     p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
     p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
-    p.a_col_stride = p.K;
+    p.gsT = d->sT; p.gsH = d->sH; p.gsW = d->sW; p.goT = -d->pT; p.goH = -d->pH; p.goW = -d->pW;
+    p.dir = 1;
+    p.a_m_stride = p.K; p.a_c_stride = taps;
+    p.k0T = p.k0H = p.k0W = 0; p.tsT = p.tsH = p.tsW = 1; p.kH = d->kH; p.kW = d->kW;
+    p.g_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
+    p.a_bytes = 4u * (unsigned)((long)d->Cout * p.K);
     p.relu = fuse_relu ? 1 : 0;
     const bool avec = (p.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
-    if (avec) return dispatch<MODE_FWD, true>(p, w, x, bias, y, (hipStream_t)stream);
-    return dispatch<MODE_FWD, false>(p, w, x, bias, y, (hipStream_t)stream);
+    return dispatch_any(p, avec, w, x, bias, y, (hipStream_t)stream);
 }
 
 extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -391,16 +428,51 @@ extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const f
     int st = conv_check(d);
     if (st) return st;
     if (!dy || !w || !dx) return ZSV_E_NULL;
-    IgemmParams p;
-    fill_common(p, d);
-    p.M = d->Cin;
-    p.P = d->N * d->Ti * d->Hi * d->Wi;
-    p.K = d->Cout * p.taps;
-    p.oS = d->Ti * d->Hi * d->Wi; p.oHW = d->Hi * d->Wi; p.oW = d->Wi;
-    p.gC = d->Cout; p.gT = d->To; p.gH = d->Ho; p.gW = d->Wo;
-    p.gS = d->To * d->Ho * d->Wo; p.gHW = d->Ho * d->Wo;
-    p.a_col_stride = p.taps;
-    return dispatch<MODE_DGRAD, false>(p, w, dy, nullptr, dx, (hipStream_t)stream);
+    const int taps_full = d->kT * d->kH * d->kW;
+    const int dims[3] = {d->Ti, d->Hi, d->Wi};
+    const int ks[3] = {d->kT, d->kH, d->kW};
+    const int ss[3] = {d->sT, d->sH, d->sW};
+    const int ps[3] = {d->pT, d->pH, d->pW};
+    // one launch per residue class of input voxels (x = s*x' + r per axis)
+    for (int rt = 0; rt < d->sT; ++rt)
+        for (int rh = 0; rh < d->sH; ++rh)
+            for (int rw = 0; rw < d->sW; ++rw) {
+                const int rr[3] = {rt, rh, rw};
+                int cdim[3], k0[3], c0[3], nt[3];
+                bool empty = false;
+                for (int a = 0; a < 3; ++a) {
+                    cdim[a] = (dims[a] - rr[a] + ss[a] - 1) / ss[a];          // voxels of this class along the axis
+                    if (cdim[a] <= 0) empty = true;
+                    k0[a] = (rr[a] + ps[a]) % ss[a];                          // first tap with matching residue
+                    c0[a] = (rr[a] + ps[a] - k0[a]) / ss[a];                  // out = x' + c0 - j
+                    nt[a] = k0[a] < ks[a] ? (ks[a] - k0[a] + ss[a] - 1) / ss[a] : 0;
+                }
+                if (empty) continue;
+                IgemmParams p = {};
+                p.M = d->Cin;
+                p.P = d->N * cdim[0] * cdim[1] * cdim[2];
+                p.nT = nt[0]; p.nH = nt[1]; p.nW = nt[2];
+                p.taps = nt[0] * nt[1] * nt[2];
+                if (p.taps == 0) { p.taps = 1; p.nT = p.nH = p.nW = 1; p.K = 0; }   // class sees no tap: dx = 0
+                else p.K = d->Cout * p.taps;
+                p.nHW = p.nH * p.nW;
+                p.cS = cdim[0] * cdim[1] * cdim[2]; p.cHW = cdim[1] * cdim[2]; p.cW = cdim[2];
+                p.oS = d->Ti * d->Hi * d->Wi; p.oHW = d->Hi * d->Wi; p.oW = d->Wi;
+                p.stT = d->sT; p.stH = d->sH; p.stW = d->sW; p.rT = rt; p.rH = rh; p.rW = rw;
+                p.gC = d->Cout; p.gT = d->To; p.gH = d->Ho; p.gW = d->Wo;
+                p.gS = d->To * d->Ho * d->Wo; p.gHW = d->Ho * d->Wo;
+                p.gsT = p.gsH = p.gsW = 1; p.goT = c0[0]; p.goH = c0[1]; p.goW = c0[2];
+                p.dir = -1;
+                p.a_m_stride = taps_full; p.a_c_stride = d->Cin * taps_full;
+                p.k0T = k0[0]; p.k0H = k0[1]; p.k0W = k0[2]; p.tsT = d->sT; p.tsH = d->sH; p.tsW = d->sW;
+                p.kH = d->kH; p.kW = d->kW;
+                p.g_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.gS);
+                p.a_bytes = 4u * (unsigned)((long)d->Cout * d->Cin * taps_full);
+                p.relu = 0;
+                st = dispatch_any(p, false, w, dy, nullptr, dx, (hipStream_t)stream);
+                if (st) return st;
+            }
+    return ZSV_OK;
 }
 
 extern "C" int zsv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t rows,
