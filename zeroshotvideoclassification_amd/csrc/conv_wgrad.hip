@@ -37,6 +37,7 @@ struct WgradParams {
     int gC, gT, gH, gW, gS, gHW;   // x geometry
     int sT, sH, sW, pT, pH, pW;
     int chunks_per_slice;          // 32-voxel chunks handled by one slice
+    unsigned x_bytes, dy_bytes;    // buffer sizes for the hardware range check
 };
 
 template <int TM, int TN, int WGM, int WGN>
@@ -55,7 +56,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
 
     __shared__ float As[2][BM * LDK];
     __shared__ float Bs[2][BN * LDK];
-    __shared__ int kinfo[BN][2];           // per k-row: gather offset, packed shifts
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,10 +66,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
     const int n0 = (blockIdx.x / tiles_m) * BN;
     const int slice = blockIdx.y;
 
-    // k-rows of this tile are fixed for the whole kernel: decode once
-    for (int r = tid; r < BN; r += 256) {
-        const int k = n0 + r;
-        int goff = 0, shifts = 31 | (31 << 8) | (31 << 16);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, prm.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY), 0, prm.dy_bytes, 0x00020000);
+
+    const int pcol = tid % BP;
+    const int prow0 = tid / BP;
+
+    // the k-rows (and dY rows) a thread stages are the same in every chunk: decode them once
+    int goff[BPASS];        // byte offset of row k inside the gathered tensor (-1: k >= K)
+    int gsel[BPASS];        // packed mask shifts  kw | (8+kh)<<8 | (16+kt)<<16
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        const int k = n0 + prow0 + RPP * j;
+        goff[j] = 0;
+        gsel[j] = 31 | (31 << 8) | (31 << 16);
         if (k < prm.K) {
             const int c = k / prm.taps;
             const int tap = k - c * prm.taps;
@@ -77,15 +87,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
             const int rr = tap - kt * prm.kHW;
             const int kh = rr / prm.kW;
             const int kw = rr - kh * prm.kW;
-            goff = c * prm.gS + kt * prm.gHW + kh * prm.gW + kw;
-            shifts = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
+            goff[j] = 4 * (c * prm.gS + kt * prm.gHW + kh * prm.gW + kw);
+            gsel[j] = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
         }
-        kinfo[r][0] = goff;
-        kinfo[r][1] = shifts;
     }
 
-    const int pcol = tid % BP;
-    const int prow0 = tid / BP;
     const int chunk_begin = slice * prm.chunks_per_slice;
     int chunk_end = chunk_begin + prm.chunks_per_slice;
     const int total_chunks = (prm.P + BP - 1) / BP;
@@ -95,40 +101,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
 
     auto load_chunk = [&](int chunk) {
         const int p = chunk * BP + pcol;
-        const bool pv = p < prm.P;
-        int dy_base = 0, x_base = 0;
+        unsigned dy_base = 0xFFFFFFFFu;
+        int x_base = 0;
         unsigned vmask = 0;
-        if (pv) {
+        if (p < prm.P) {
             const int n = p / prm.oS;
             int r = p - n * prm.oS;
-            dy_base = n * prm.M * prm.oS + r;
+            dy_base = 4u * (unsigned)(n * prm.M * prm.oS + r);
             const int ot = r / prm.oHW;
             r -= ot * prm.oHW;
             const int oh = r / prm.oW;
             const int ow = r - oh * prm.oW;
             const int t0 = ot * prm.sT - prm.pT, h0 = oh * prm.sH - prm.pH, w0 = ow * prm.sW - prm.pW;
-            x_base = n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0;
+            x_base = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
             for (int k = 0; k < prm.kW; ++k) vmask |= ((unsigned)(w0 + k) < (unsigned)prm.gW) << k;
             for (int k = 0; k < prm.kH; ++k) vmask |= ((unsigned)(h0 + k) < (unsigned)prm.gH) << (8 + k);
             for (int k = 0; k < prm.kT; ++k) vmask |= ((unsigned)(t0 + k) < (unsigned)prm.gT) << (16 + k);
         }
+        const unsigned row_bytes = 4u * (unsigned)prm.oS;
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
-            const int row = prow0 + RPP * j;
-            const bool ok = pv && (m0 + row < prm.M);
-            const int off = ok ? dy_base + (m0 + row) * prm.oS : 0;
-            const float v = DY[off];
-            areg[j] = ok ? v : 0.f;
+            const int row = m0 + prow0 + RPP * j;
+            // rows >= M land beyond the buffer only for the last clip; mask them explicitly
+            const unsigned off = (row < prm.M) ? dy_base + (unsigned)row * row_bytes : 0xFFFFFFFFu;
+            areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)(off | (dy_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u)), 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < BPASS; ++j) {
-            const int row = prow0 + RPP * j;
-            const int goff = kinfo[row][0];
-            const int sh = kinfo[row][1];
+            const int sh = gsel[j];
             const unsigned ok = (vmask >> (sh & 31)) & (vmask >> ((sh >> 8) & 31)) & (vmask >> ((sh >> 16) & 31)) & 1u;
-            const int off = ok ? x_base + goff : 0;
-            const float v = X[off];
-            breg[j] = ok ? v : 0.f;
+            const unsigned off = (unsigned)(x_base + goff[j]) | (ok - 1u);
+            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)off, 0, 0));
         }
     };
     auto store_chunk = [&](int buf) {
@@ -144,7 +147,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();   // kinfo visible
     if (chunk_begin < chunk_end) {
         load_chunk(chunk_begin);
         store_chunk(0);
@@ -160,17 +162,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
 #pragma unroll
-        for (int kk = 0; kk < BP / 4; ++kk) {
-            float a[TM], b[TN];
+        for (int half = 0; half < 2; ++half) {
+            float a[BP / 8][TM], b[BP / 8][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(wm0 + 16 * i + frag_r) * LDK + kk * 4 + frag_k];
+            for (int kk = 0; kk < BP / 8; ++kk) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(wn0 + 16 * j + frag_r) * LDK + kk * 4 + frag_k];
+                for (int i = 0; i < TM; ++i) a[kk][i] = as[(wm0 + 16 * i + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[kk][j] = bs[(wn0 + 16 * j + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // fragment burst stays ahead of the MFMA chain
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int kk = 0; kk < BP / 8; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            }
         }
         if (more) store_chunk(cur ^ 1);
         __syncthreads();
@@ -264,6 +273,8 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
     p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.chunks_per_slice = pl.chunks_per_slice;
+    p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
+    p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
 
     float* out = pl.slices > 1 ? (float*)workspace : dw;
     const dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.slices);
