@@ -51,12 +51,17 @@ const char* zsv_status_string(int status);
 const char* zsv_version(void);
 
 /* ---- convolution (aten::conv3d and its autograd formulas) ------------------- */
-/* y = conv3d(x, w) (+ bias[c]) (relu optional, for network.py:147-162 `relu(conv(x))`). */
+/* y = conv3d(x, w) (+ bias[c]) (relu optional, for network.py:147-162 `relu(conv(x))`).
+ * `workspace` holds the weights re-packed tap-major for the fast kernel (query the size;
+ * 0 means the call needs none).  It must be 16-byte aligned. */
+size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
-                   float* y, int fuse_relu, void* stream);
-/* dx = conv3d_input_grad(dy, w): what autograd runs for every conv but the first. */
+                   float* y, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv3d_input_grad(dy, w): what autograd runs for every conv but the first.  Strided
+ * convolutions are solved per residue class of input voxels (no multiplies by inserted zeros). */
+size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* dw = conv3d_weight_grad(x, dy).  Deterministic: position range is cut into a fixed
  * number of slices, each slice writes a partial slab into `workspace`, a second kernel
  * sums the slabs in slice order. */
@@ -121,10 +126,13 @@ int zsv_maxpool3d_bwd(const float* dy, const int32_t* argmax, int32_t N, int32_t
 /* ---- dense head ----------------------------------------------------------------- */
 /* nn.Linear (network.py:611-616 MLP, :120,132 fc6/regressor): y = x W^T + b, optional ReLU.
  * x (rows, in), w (out, in), y (rows, out).  Implemented on the same MFMA GEMM core. */
+size_t zsv_linear_fwd_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features);
 int zsv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t rows,
-                   int32_t in_features, int32_t out_features, int fuse_relu, void* stream);
-int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int32_t rows,
-                     int32_t in_features, int32_t out_features, void* stream);
+                   int32_t in_features, int32_t out_features, int fuse_relu, void* workspace,
+                   size_t workspace_bytes, void* stream);
+size_t zsv_linear_dgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features);
+int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int32_t rows, int32_t in_features,
+                     int32_t out_features, void* workspace, size_t workspace_bytes, void* stream);
 size_t zsv_linear_wgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features);
 int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
                      int32_t in_features, int32_t out_features, void* workspace,

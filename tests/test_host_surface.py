@@ -32,8 +32,8 @@ def test_workspace_queries_need_no_gpu():
     assert lib.zsv_conv3d_wgrad_workspace_bytes(ctypes.byref(d)) > 0
     bad = _lib.ConvDesc(22, 64, 16, 56, 56, 144, 16, 57, 56, 1, 3, 3, 1, 1, 1, 0, 1, 1)   # Ho inconsistent
     assert lib.zsv_conv3d_wgrad_workspace_bytes(ctypes.byref(bad)) == 0
-    assert lib.zsv_conv3d_fwd(ctypes.byref(bad), None, None, None, None, 0, None) == 1      # ZSV_E_BAD_SHAPE
-    assert lib.zsv_conv3d_fwd(ctypes.byref(d), None, None, None, None, 0, None) == 2        # ZSV_E_NULL
+    assert lib.zsv_conv3d_fwd(ctypes.byref(bad), None, None, None, None, 0, None, 0, None) == 1      # ZSV_E_BAD_SHAPE
+    assert lib.zsv_conv3d_fwd(ctypes.byref(d), None, None, None, None, 0, None, 0, None) == 2        # ZSV_E_NULL
     assert lib.zsv_bn_workspace_bytes(22, 144, 50176) > 0
     assert lib.zsv_bn_workspace_bytes(0, 144, 50176) == 0
 

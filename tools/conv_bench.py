@@ -67,9 +67,12 @@ def main():
         nb = lib.zsv_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
         flops = 2.0 * d.N * d.Cout * d.To * d.Ho * d.Wo * cin * k[0] * k[1] * k[2]
+        nf = lib.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d))
+        nd = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+        wsf = torch.empty(max(nf, nd, 16), dtype=torch.uint8, device=dev)
         calls = {
-            "fwd": lambda: lib.zsv_conv3d_fwd(ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, stream),
-            "dgrad": lambda: lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), stream),
+            "fwd": lambda: lib.zsv_conv3d_fwd(ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, wsf.data_ptr(), nf, stream),
+            "dgrad": lambda: lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), wsf.data_ptr(), nd, stream),
             "wgrad": lambda: lib.zsv_conv3d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, stream),
         }
         for kind in args.kinds.split(","):

@@ -28,8 +28,10 @@ _P = c_void_p
 SIGNATURES = {
     "zsv_status_string": (c_char_p, [c_int]),
     "zsv_version": (c_char_p, []),
-    "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P]),
-    "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
+    "zsv_conv3d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "zsv_conv3d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "zsv_channel_sum_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
@@ -48,8 +50,10 @@ SIGNATURES = {
     "zsv_meanpool_bwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_maxpool3d_fwd": (c_int, [_P] + [c_int32] * 14 + [_P, _P, _P]),
     "zsv_maxpool3d_bwd": (c_int, [_P, _P] + [c_int32] * 14 + [_P, _P]),
-    "zsv_linear_fwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int, _P]),
-    "zsv_linear_dgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P]),
+    "zsv_linear_fwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "zsv_linear_fwd": (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int, _P, c_size_t, _P]),
+    "zsv_linear_dgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "zsv_linear_dgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "zsv_linear_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "zsv_linear_wgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),

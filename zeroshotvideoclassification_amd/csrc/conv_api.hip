@@ -1,0 +1,160 @@
+// conv_api.hip -- C-ABI entry points of the forward / input-gradient convolution (gfx950).
+//
+// Builds the launch geometry for aten::conv3d (resnet.py:23-30,40-52,63-70,170,181,184,270;
+// network.py:102-117) and its dgrad, then picks a kernel family:
+//   * conv_tap.hip   (tap-major K order, packed weights, zero per-element address math) when the
+//                    gathered tensor has >= 16 channels and <= 31 taps -- every layer but the stems;
+//   * conv_igemm.hip (generic (channel, tap) order) otherwise (3-channel stems, 7x7 kernels).
+#include <stdlib.h>
+#include "conv_params.h"
+
+using namespace zsv;
+
+namespace {
+
+void fwd_params(IgemmParams& p, const zsv_conv_desc* d, int fuse_relu) {
+    p = IgemmParams{};
+    const int taps = d->kT * d->kH * d->kW;
+    p.M = d->Cout;
+    p.P = d->N * d->To * d->Ho * d->Wo;
+    p.K = d->Cin * taps;
+    p.taps = taps; p.nHW = d->kH * d->kW; p.nW = d->kW; p.nT = d->kT; p.nH = d->kH;
+    p.cS = d->To * d->Ho * d->Wo; p.cHW = d->Ho * d->Wo; p.cW = d->Wo;
+    p.oS = p.cS; p.oHW = p.cHW; p.oW = p.cW;
+    p.stT = p.stH = p.stW = 1; p.rT = p.rH = p.rW = 0;
+    p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
+    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
+    p.gsT = d->sT; p.gsH = d->sH; p.gsW = d->sW; p.goT = -d->pT; p.goH = -d->pH; p.goW = -d->pW;
+    p.dir = 1;
+    p.a_m_stride = p.K; p.a_c_stride = taps;
+    p.k0T = p.k0H = p.k0W = 0; p.tsT = p.tsH = p.tsW = 1; p.kH = d->kH; p.kW = d->kW;
+    p.g_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
+    p.a_bytes = 4u * (unsigned)((long)d->Cout * p.K);
+    p.relu = fuse_relu ? 1 : 0;
+}
+
+// dgrad of a strided convolution = one dense stride-1 problem per residue class of input voxels
+// (x = s*x' + r per axis).  Returns false when the class has no voxel.
+bool dgrad_class_params(IgemmParams& p, const zsv_conv_desc* d, int rt, int rh, int rw) {
+    const int taps_full = d->kT * d->kH * d->kW;
+    const int dims[3] = {d->Ti, d->Hi, d->Wi};
+    const int ks[3] = {d->kT, d->kH, d->kW};
+    const int ss[3] = {d->sT, d->sH, d->sW};
+    const int ps[3] = {d->pT, d->pH, d->pW};
+    const int rr[3] = {rt, rh, rw};
+    int cdim[3], k0[3], c0[3], nt[3];
+    for (int a = 0; a < 3; ++a) {
+        cdim[a] = (dims[a] - rr[a] + ss[a] - 1) / ss[a];          // voxels of this class along the axis
+        if (cdim[a] <= 0) return false;
+        k0[a] = (rr[a] + ps[a]) % ss[a];                          // first tap with matching residue
+        c0[a] = (rr[a] + ps[a] - k0[a]) / ss[a];                  // out = x' + c0 - j
+        nt[a] = k0[a] < ks[a] ? (ks[a] - k0[a] + ss[a] - 1) / ss[a] : 0;
+    }
+    p = IgemmParams{};
+    p.M = d->Cin;
+    p.P = d->N * cdim[0] * cdim[1] * cdim[2];
+    p.nT = nt[0]; p.nH = nt[1]; p.nW = nt[2];
+    p.taps = nt[0] * nt[1] * nt[2];
+    if (p.taps == 0) { p.taps = 1; p.nT = p.nH = p.nW = 1; p.K = 0; }   // class sees no tap: dx = 0
+    else p.K = d->Cout * p.taps;
+    p.nHW = p.nH * p.nW;
+    p.cS = cdim[0] * cdim[1] * cdim[2]; p.cHW = cdim[1] * cdim[2]; p.cW = cdim[2];
+    p.oS = d->Ti * d->Hi * d->Wi; p.oHW = d->Hi * d->Wi; p.oW = d->Wi;
+    p.stT = d->sT; p.stH = d->sH; p.stW = d->sW; p.rT = rt; p.rH = rh; p.rW = rw;
+    p.gC = d->Cout; p.gT = d->To; p.gH = d->Ho; p.gW = d->Wo;
+    p.gS = d->To * d->Ho * d->Wo; p.gHW = d->Ho * d->Wo;
+    p.gsT = p.gsH = p.gsW = 1; p.goT = c0[0]; p.goH = c0[1]; p.goW = c0[2];
+    p.dir = -1;
+    p.a_m_stride = taps_full; p.a_c_stride = d->Cin * taps_full;
+    p.k0T = k0[0]; p.k0H = k0[1]; p.k0W = k0[2]; p.tsT = d->sT; p.tsH = d->sH; p.tsW = d->sW;
+    p.kH = d->kH; p.kW = d->kW;
+    p.g_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.gS);
+    p.a_bytes = 4u * (unsigned)((long)d->Cout * d->Cin * taps_full);
+    p.relu = 0;
+    return true;
+}
+
+const zsv_conv_desc linear_desc(int32_t rows, int32_t in_features, int32_t out_features) {
+    zsv_conv_desc d = {rows, in_features, 1, 1, 1, out_features, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
+    return d;
+}
+
+}  // namespace
+
+extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    IgemmParams p;
+    fwd_params(p, d, 0);
+    return igemm_tap_applicable(p) ? igemm_tap_workspace_bytes(p) : 0;
+}
+
+extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                              float* y, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream) {
+    int st = conv_check(d);
+    if (st) return st;
+    if (!x || !w || !y) return ZSV_E_NULL;
+    IgemmParams p;
+    fwd_params(p, d, fuse_relu);
+    if (igemm_tap_applicable(p))
+        return igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
+    const bool avec = (p.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    return igemm_generic(p, avec, w, x, bias, y, (hipStream_t)stream);
+}
+
+extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    size_t need = 0;
+    IgemmParams p;
+    for (int rt = 0; rt < d->sT; ++rt)
+        for (int rh = 0; rh < d->sH; ++rh)
+            for (int rw = 0; rw < d->sW; ++rw)
+                if (dgrad_class_params(p, d, rt, rh, rw) && igemm_tap_applicable(p)) {
+                    const size_t b = igemm_tap_workspace_bytes(p);
+                    if (b > need) need = b;
+                }
+    return need;
+}
+
+extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    int st = conv_check(d);
+    if (st) return st;
+    if (!dy || !w || !dx) return ZSV_E_NULL;
+    IgemmParams p;
+    // one launch per residue class; the classes reuse the (stream-ordered) weight workspace
+    for (int rt = 0; rt < d->sT; ++rt)
+        for (int rh = 0; rh < d->sH; ++rh)
+            for (int rw = 0; rw < d->sW; ++rw) {
+                if (!dgrad_class_params(p, d, rt, rh, rw)) continue;
+                if (igemm_tap_applicable(p))
+                    st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
+                else
+                    st = igemm_generic(p, false, w, dy, nullptr, dx, (hipStream_t)stream);
+                if (st) return st;
+            }
+    return ZSV_OK;
+}
+
+extern "C" size_t zsv_linear_fwd_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {
+    const zsv_conv_desc d = linear_desc(rows, in_features, out_features);
+    return zsv_conv3d_fwd_workspace_bytes(&d);
+}
+
+extern "C" int zsv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t rows,
+                              int32_t in_features, int32_t out_features, int fuse_relu, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    const zsv_conv_desc d = linear_desc(rows, in_features, out_features);
+    return zsv_conv3d_fwd(&d, x, w, bias, y, fuse_relu, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t zsv_linear_dgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {
+    const zsv_conv_desc d = linear_desc(rows, in_features, out_features);
+    return zsv_conv3d_dgrad_workspace_bytes(&d);
+}
+
+extern "C" int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int32_t rows, int32_t in_features,
+                                int32_t out_features, void* workspace, size_t workspace_bytes, void* stream) {
+    const zsv_conv_desc d = linear_desc(rows, in_features, out_features);
+    return zsv_conv3d_dgrad(&d, dy, w, dx, workspace, workspace_bytes, stream);
+}

@@ -36,37 +36,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "zsv_hip.h"
-#include "zsv_common.h"
+#include "conv_params.h"
 
 namespace zsv {
-
-struct IgemmParams {
-    int M;          // rows: channels produced (Cout fwd / Cin dgrad)
-    int P;          // columns: voxels of this launch (N * class grid)
-    int K;          // reduction: Cred * taps
-    // taps of this launch (the whole kernel for fwd, one residue class for dgrad)
-    int taps, nHW, nW, nT, nH;
-    // column decode over the class grid (cT, cH, cW)
-    int cS, cHW, cW;
-    // produced tensor (full) and where class voxel (ct, ch, cw) lands in it
-    int oS, oHW, oW;
-    int stT, stH, stW, rT, rH, rW;
-    // gathered tensor and the gather rule: coord = c * gs + go + dir * j, valid in [0, g)
-    int gC, gT, gH, gW, gS, gHW;
-    int gsT, gsH, gsW, goT, goH, goW;
-    int dir;
-    // weights: A(m, k = (c, tap)) = a[m * a_m_stride + c * a_c_stride + tap_full]
-    //   tap_full = ((k0T + tsT*jt) * kH + k0H + tsH*jh) * kW + k0W + tsW*jw
-    int a_m_stride, a_c_stride;
-    int k0T, k0H, k0W, tsT, tsH, tsW, kH, kW;
-    unsigned g_bytes, a_bytes;     // buffer sizes for the hardware range check
-    int relu;
-};
-
-template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
-
-__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------
 // AVEC: A rows are contiguous in k and 16-B aligned (forward, K % 4 == 0): float4 staging.
@@ -101,13 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
     const int wm0 = (wave / WGN) * (16 * TM);
     const int wn0 = (wave % WGN) * (16 * TN);
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous range
-    int tile;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
     const int m0 = (tile % tiles_m) * BM;
     const int n0 = (tile / tiles_m) * BN;
 
@@ -287,33 +253,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams prm,
         __syncthreads();
     }
 
-    // ---- epilogue: acc(i,j)[r] -> C[n][m][sp]; rows m = .. + 4*(lane>>4) + r, col = lane&15
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int p = n0 + wn0 + 16 * j + frag_col;
-        if (p >= prm.P) continue;
-        const int n = p / prm.cS;
-        int r = p - n * prm.cS;
-        const int ct = r / prm.cHW;
-        r -= ct * prm.cHW;
-        const int chh = r / prm.cW;
-        const int cw = r - chh * prm.cW;
-        const int sp = (ct * prm.stT + prm.rT) * prm.oHW + (chh * prm.stH + prm.rH) * prm.oW + cw * prm.stW + prm.rW;
-        float* cbase = C + (size_t)n * prm.M * prm.oS + sp;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int m = m0 + wm0 + 16 * i + 4 * frag_row + r4;
-                if (m < prm.M) {
-                    float v = acc[i][j][r4];
-                    if (bias != nullptr) v += bias[m];
-                    if (prm.relu) v = fmaxf(v, 0.f);
-                    cbase[(size_t)m * prm.oS] = v;
-                }
-            }
-        }
-    }
+    store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
 }
 
 // ---------------------------------------------------------------------------------
@@ -363,8 +303,8 @@ static int dispatch(const IgemmParams& prm, const float* A, const float* G, cons
     }
 }
 
-static int dispatch_any(const IgemmParams& prm, bool avec, const float* A, const float* G, const float* bias,
-                        float* C, hipStream_t stream) {
+int igemm_generic(const IgemmParams& prm, bool avec, const float* A, const float* G, const float* bias,
+                  float* C, hipStream_t stream) {
     const bool wide = prm.taps > 31;
     if (wide) {
         // the 7x7 stems: never vectorised A (K = 147 / 441)
@@ -393,96 +333,3 @@ int conv_check(const zsv_conv_desc* d) {
 }
 
 }  // namespace zsv
-
-using namespace zsv;
-
-extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
-                              float* y, int fuse_relu, void* stream) {
-    int st = conv_check(d);
-    if (st) return st;
-    if (!x || !w || !y) return ZSV_E_NULL;
-    IgemmParams p = {};
-    const int taps = d->kT * d->kH * d->kW;
-    p.M = d->Cout;
-    p.P = d->N * d->To * d->Ho * d->Wo;
-    p.K = d->Cin * taps;
-    p.taps = taps; p.nHW = d->kH * d->kW; p.nW = d->kW; p.nT = d->kT; p.nH = d->kH;
-    p.cS = d->To * d->Ho * d->Wo; p.cHW = d->Ho * d->Wo; p.cW = d->Wo;
-    p.oS = p.cS; p.oHW = p.cHW; p.oW = p.cW;
-    p.stT = p.stH = p.stW = 1; p.rT = p.rH = p.rW = 0;
-    p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
-    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
-    p.gsT = d->sT; p.gsH = d->sH; p.gsW = d->sW; p.goT = -d->pT; p.goH = -d->pH; p.goW = -d->pW;
-    p.dir = 1;
-    p.a_m_stride = p.K; p.a_c_stride = taps;
-    p.k0T = p.k0H = p.k0W = 0; p.tsT = p.tsH = p.tsW = 1; p.kH = d->kH; p.kW = d->kW;
-    p.g_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
-    p.a_bytes = 4u * (unsigned)((long)d->Cout * p.K);
-    p.relu = fuse_relu ? 1 : 0;
-    const bool avec = (p.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
-    return dispatch_any(p, avec, w, x, bias, y, (hipStream_t)stream);
-}
-
-extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
-                                void* stream) {
-    int st = conv_check(d);
-    if (st) return st;
-    if (!dy || !w || !dx) return ZSV_E_NULL;
-    const int taps_full = d->kT * d->kH * d->kW;
-    const int dims[3] = {d->Ti, d->Hi, d->Wi};
-    const int ks[3] = {d->kT, d->kH, d->kW};
-    const int ss[3] = {d->sT, d->sH, d->sW};
-    const int ps[3] = {d->pT, d->pH, d->pW};
-    // one launch per residue class of input voxels (x = s*x' + r per axis)
-    for (int rt = 0; rt < d->sT; ++rt)
-        for (int rh = 0; rh < d->sH; ++rh)
-            for (int rw = 0; rw < d->sW; ++rw) {
-                const int rr[3] = {rt, rh, rw};
-                int cdim[3], k0[3], c0[3], nt[3];
-                bool empty = false;
-                for (int a = 0; a < 3; ++a) {
-                    cdim[a] = (dims[a] - rr[a] + ss[a] - 1) / ss[a];          // voxels of this class along the axis
-                    if (cdim[a] <= 0) empty = true;
-                    k0[a] = (rr[a] + ps[a]) % ss[a];                          // first tap with matching residue
-                    c0[a] = (rr[a] + ps[a] - k0[a]) / ss[a];                  // out = x' + c0 - j
-                    nt[a] = k0[a] < ks[a] ? (ks[a] - k0[a] + ss[a] - 1) / ss[a] : 0;
-                }
-                if (empty) continue;
-                IgemmParams p = {};
-                p.M = d->Cin;
-                p.P = d->N * cdim[0] * cdim[1] * cdim[2];
-                p.nT = nt[0]; p.nH = nt[1]; p.nW = nt[2];
-                p.taps = nt[0] * nt[1] * nt[2];
-                if (p.taps == 0) { p.taps = 1; p.nT = p.nH = p.nW = 1; p.K = 0; }   // class sees no tap: dx = 0
-                else p.K = d->Cout * p.taps;
-                p.nHW = p.nH * p.nW;
-                p.cS = cdim[0] * cdim[1] * cdim[2]; p.cHW = cdim[1] * cdim[2]; p.cW = cdim[2];
-                p.oS = d->Ti * d->Hi * d->Wi; p.oHW = d->Hi * d->Wi; p.oW = d->Wi;
-                p.stT = d->sT; p.stH = d->sH; p.stW = d->sW; p.rT = rt; p.rH = rh; p.rW = rw;
-                p.gC = d->Cout; p.gT = d->To; p.gH = d->Ho; p.gW = d->Wo;
-                p.gS = d->To * d->Ho * d->Wo; p.gHW = d->Ho * d->Wo;
-                p.gsT = p.gsH = p.gsW = 1; p.goT = c0[0]; p.goH = c0[1]; p.goW = c0[2];
-                p.dir = -1;
-                p.a_m_stride = taps_full; p.a_c_stride = d->Cin * taps_full;
-                p.k0T = k0[0]; p.k0H = k0[1]; p.k0W = k0[2]; p.tsT = d->sT; p.tsH = d->sH; p.tsW = d->sW;
-                p.kH = d->kH; p.kW = d->kW;
-                p.g_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.gS);
-                p.a_bytes = 4u * (unsigned)((long)d->Cout * d->Cin * taps_full);
-                p.relu = 0;
-                st = dispatch_any(p, false, w, dy, nullptr, dx, (hipStream_t)stream);
-                if (st) return st;
-            }
-    return ZSV_OK;
-}
-
-extern "C" int zsv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int32_t rows,
-                              int32_t in_features, int32_t out_features, int fuse_relu, void* stream) {
-    zsv_conv_desc d = {rows, in_features, 1, 1, 1, out_features, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
-    return zsv_conv3d_fwd(&d, x, w, bias, y, fuse_relu, stream);
-}
-
-extern "C" int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int32_t rows,
-                                int32_t in_features, int32_t out_features, void* stream) {
-    zsv_conv_desc d = {rows, in_features, 1, 1, 1, out_features, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0};
-    return zsv_conv3d_dgrad(&d, dy, w, dx, stream);
-}

@@ -1,0 +1,87 @@
+// conv_params.h -- launch geometry shared by the convolution kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "zsv_hip.h"
+#include "zsv_common.h"
+
+namespace zsv {
+
+struct IgemmParams {
+    int M;          // rows: channels produced (Cout fwd / Cin dgrad)
+    int P;          // columns: voxels of this launch (N * class grid)
+    int K;          // reduction: Cred * taps
+    // taps of this launch (the whole kernel for fwd, one residue class for dgrad)
+    int taps, nHW, nW, nT, nH;
+    // column decode over the class grid (cT, cH, cW)
+    int cS, cHW, cW;
+    // produced tensor (full) and where class voxel (ct, ch, cw) lands in it
+    int oS, oHW, oW;
+    int stT, stH, stW, rT, rH, rW;
+    // gathered tensor and the gather rule: coord = c * gs + go + dir * j, valid in [0, g)
+    int gC, gT, gH, gW, gS, gHW;
+    int gsT, gsH, gsW, goT, goH, goW;
+    int dir;
+    // weights: A(m, k = (c, tap)) = a[m * a_m_stride + c * a_c_stride + tap_full]
+    //   tap_full = ((k0T + tsT*jt) * kH + k0H + tsH*jh) * kW + k0W + tsW*jw
+    int a_m_stride, a_c_stride;
+    int k0T, k0H, k0W, tsT, tsH, tsW, kH, kW;
+    unsigned g_bytes, a_bytes;     // buffer sizes for the hardware range check
+    int relu;
+};
+
+template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
+
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+
+// ---- shared epilogue: accumulator tiles -> C[n][m][sp] (+bias, ReLU) -----------------------
+// acc(i,j)[r]: row m = m_base + 16*i + 4*(lane>>4) + r, column p = p_base + 16*j + (lane&15)
+template <int TM, int TN>
+__device__ __forceinline__ void store_tiles(const IgemmParams& prm, const f32x4 (&acc)[TM][TN], int m_base, int p_base,
+                                            int lane, const float* __restrict__ bias, float* __restrict__ C) {
+    const int frag_row = lane >> 4, frag_col = lane & 15;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = p_base + 16 * j + frag_col;
+        if (p >= prm.P) continue;
+        const int n = p / prm.cS;
+        int r = p - n * prm.cS;
+        const int ct = r / prm.cHW;
+        r -= ct * prm.cHW;
+        const int chh = r / prm.cW;
+        const int cw = r - chh * prm.cW;
+        const int sp = (ct * prm.stT + prm.rT) * prm.oHW + (chh * prm.stH + prm.rH) * prm.oW + cw * prm.stW + prm.rW;
+        float* cbase = C + (size_t)n * prm.M * prm.oS + sp;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int m = m_base + 16 * i + 4 * frag_row + r4;
+                if (m < prm.M) {
+                    float v = acc[i][j][r4];
+                    if (bias != nullptr) v += bias[m];
+                    if (prm.relu) v = fmaxf(v, 0.f);
+                    cbase[(size_t)m * prm.oS] = v;
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous tile range
+__device__ __forceinline__ int xcd_tile(int nwg, int bid) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// host-side entry points of the two kernel families
+int igemm_generic(const IgemmParams& prm, bool avec, const float* A, const float* G, const float* bias, float* C,
+                  hipStream_t stream);
+bool igemm_tap_applicable(const IgemmParams& prm);
+size_t igemm_tap_workspace_bytes(const IgemmParams& prm);
+int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
+              const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int conv_check(const zsv_conv_desc* d);
+
+}  // namespace zsv

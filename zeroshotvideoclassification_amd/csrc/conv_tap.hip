@@ -1,0 +1,292 @@
+// conv_tap.hip -- tap-major implicit-GEMM convolution (forward and dgrad) for gfx950.
+//
+// Same GEMM view, tile shapes, MFMA (v_mfma_f32_16x16x4_f32, bit-exact fp32) and LDS images
+// as conv_igemm.hip, but the reduction index is ordered (tap, channel) instead of
+// (channel, tap), and a K-chunk is "one tap x 16 consecutive channels".  That removes the
+// per-element address arithmetic from the hot loop:
+//
+//   * gathered slab B: all 16 rows of a chunk share the tap, so a lane evaluates its voxel's
+//     validity bit ONCE per chunk and builds one voffset (or 0xFFFFFFFF, which the buffer
+//     range check turns into the zero padding); the 16 rows differ only by channel, which
+//     goes into the buffer load's scalar offset operand.  8 `buffer_load_dword` per lane per
+//     chunk cost 4 VALU in total (the generic kernel spends ~6 per load).
+//   * weight panel A: the weights are re-packed once per call into Wp[tap][channel][m]
+//     (m contiguous, padded to whole tiles and zero-filled), so a chunk's 16 x BM panel is a
+//     plain 2-D block: 16-B global loads, 16-B LDS stores, no transposition, no masks.
+//     Packing reads + writes the weight tensor once (<= 42 MB for the largest layer,
+//     ~10 us) against >= 0.3 ms of convolution.
+//   * no row-decode table, no per-row v_readfirstlane: the chunk -> (tap, channel block)
+//     walk lives in SGPRs.
+//
+// Used for every layer whose gathered tensor has >= 16 channels and at most 31 taps; the
+// 3-channel 7x7 stems stay on the generic kernel.
+#include <stdlib.h>
+#include "conv_params.h"
+
+namespace zsv {
+
+// Wp[(tap * Cpad + c) * Mp + m] = W[m * w_m_stride + c * w_c_stride + tap_full(tap)]  (0 in the padding)
+__global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, const float* __restrict__ W,
+                                                           float* __restrict__ Wp, int w_m_stride, int w_c_stride,
+                                                           int Cpad, int Mp, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i % Mp);
+        const long rc = i / Mp;
+        const int c = (int)(rc % Cpad);
+        const int tap = (int)(rc / Cpad);
+        float v = 0.f;
+        if (m < prm.M && c < prm.gC) {
+            const int jt = tap / prm.nHW;
+            const int r = tap - jt * prm.nHW;
+            const int jh = r / prm.nW;
+            const int jw = r - jh * prm.nW;
+            const int tap_full = ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
+            v = W[(size_t)m * w_m_stride + (size_t)c * w_c_stride + tap_full];
+        }
+        Wp[i] = v;
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const float* __restrict__ Wp,
+                                                       const float* __restrict__ G, const float* __restrict__ bias,
+                                                       float* __restrict__ C, int tiles_m, int Mp, int nblk) {
+    constexpr int BM = 16 * TM * WGM;
+    constexpr int BN = 16 * TN * WGN;
+    constexpr int BK = 16;
+    constexpr int LDA = LdPad<BM>::value;
+    constexpr int LDB = LdPad<BN>::value;
+    constexpr int NT = 256;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(BN == 64 || BN == 128 || BN == 256, "BN must divide the workgroup");
+    static_assert(BM % 4 == 0 && LDA % 4 == 0, "16-B weight stores");
+    constexpr int BROWS = NT / BN;
+    constexpr int BPASS = BK / BROWS;
+    constexpr int AQ = BM / 4;                           // float4 per k-row of the weight panel
+    constexpr int AVPASS = (BK * AQ + NT - 1) / NT;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+    __shared__ int tapoff[32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = sgpr(tid >> 6);
+    const int wm0 = (wave / WGN) * (16 * TM);
+    const int wn0 = (wave % WGN) * (16 * TN);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int m0 = (tile % tiles_m) * BM;
+    const int n0 = (tile / tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, prm.g_bytes, 0x00020000);
+
+    // byte offset of each tap inside the gathered tensor (signed; dgrad walks backwards)
+    if (tid < prm.taps) {
+        const int jt = tid / prm.nHW;
+        const int r = tid - jt * prm.nHW;
+        const int jh = r / prm.nW;
+        const int jw = r - jh * prm.nW;
+        tapoff[tid] = 4 * prm.dir * (jt * prm.gHW + jh * prm.gW + jw);
+    }
+
+    // ---- per-thread gather column: voxel -> base byte offset + tap-validity bits -----------
+    const int bcol = tid % BN;
+    const int brow0 = sgpr(tid / BN);
+    int base_bytes = 0;
+    unsigned vmask = 0;
+    {
+        const int p = n0 + bcol;
+        if (p < prm.P) {
+            const int n = p / prm.cS;
+            int r = p - n * prm.cS;
+            const int ct = r / prm.cHW;
+            r -= ct * prm.cHW;
+            const int ch = r / prm.cW;
+            const int cw = r - ch * prm.cW;
+            const int t0 = ct * prm.gsT + prm.goT, h0 = ch * prm.gsH + prm.goH, w0 = cw * prm.gsW + prm.goW;
+            base_bytes = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
+            unsigned mw = 0, mh = 0, mt = 0;
+            for (int j = 0; j < prm.nW; ++j) mw |= ((unsigned)(w0 + prm.dir * j) < (unsigned)prm.gW) << j;
+            for (int j = 0; j < prm.nH; ++j) mh |= ((unsigned)(h0 + prm.dir * j) < (unsigned)prm.gH) << j;
+            for (int j = 0; j < prm.nT; ++j) mt |= ((unsigned)(t0 + prm.dir * j) < (unsigned)prm.gT) << j;
+            int tap = 0;
+            for (int a = 0; a < prm.nT; ++a)
+                for (int b = 0; b < prm.nH; ++b)
+                    for (int c = 0; c < prm.nW; ++c, ++tap)
+                        vmask |= (((mt >> a) & (mh >> b) & (mw >> c)) & 1u) << tap;
+        }
+    }
+
+    // ---- weight panel: this thread's float4 slots (fixed for the whole kernel) --------------
+    const float* a_src[AVPASS];
+    int a_dst[AVPASS];
+#pragma unroll
+    for (int j = 0; j < AVPASS; ++j) {
+        // slots beyond the panel wrap around: a few threads stage one slot twice (same value,
+        // same LDS address) instead of branching -- a conditional here sends `areg` to scratch
+        const int e = (tid + NT * j) % (BK * AQ);
+        const int r = e / AQ, c4 = e % AQ;
+        a_src[j] = Wp + (size_t)r * Mp + m0 + 4 * c4;
+        a_dst[j] = r * LDA + 4 * c4;
+    }
+    const size_t a_chunk_stride = (size_t)BK * Mp;
+    const int ch_bytes = 4 * prm.gS;                     // one channel of the gathered tensor
+
+    float breg[BPASS];
+    f32x4 areg[AVPASS];       // native vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
+
+    auto load_chunk = [&](int chunk, int tap, int cb) {
+        const int toff = sgpr(tapoff[tap]);
+        const unsigned ok = (vmask >> tap) & 1u;
+        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);       // padded tap -> 0xFFFFFFFF -> 0.0f
+        const int ci0 = cb * BK;
+        if (ci0 + BK <= prm.gC) {
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                const int ci = ci0 + brow0 + BROWS * j;
+                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)voff, ci * ch_bytes, 0));
+            }
+        } else {                                           // last channel block of a tap: rows >= gC are zero
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                const int ci = ci0 + brow0 + BROWS * j;
+                const unsigned v = ci < prm.gC ? voff : OOB;
+                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AVPASS; ++j)
+            areg[j] = *reinterpret_cast<const f32x4*>(a_src[j] + (size_t)chunk * a_chunk_stride);
+    };
+
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) Bs[buf][(brow0 + BROWS * j) * LDB + bcol] = breg[j];
+#pragma unroll
+        for (int j = 0; j < AVPASS; ++j) *reinterpret_cast<f32x4*>(&As[buf][a_dst[j]]) = areg[j];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (prm.K > 0) ? prm.taps * nblk : 0;
+    __syncthreads();                      // tapoff visible
+    if (nchunks > 0) {
+        load_chunk(0, 0, 0);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    const int frag_row = lane >> 4;
+    const int frag_col = lane & 15;
+    int ld_tap = 0, ld_cb = 0;            // (tap, channel block) of the chunk being loaded: walks in SGPRs
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        const bool more = (ch + 1) < nchunks;
+        if (more) {
+            if (++ld_cb == nblk) { ld_cb = 0; ++ld_tap; }
+            load_chunk(ch + 1, ld_tap, ld_cb);
+        }
+        const float* as = &As[cur][0];
+        const float* bs = &Bs[cur][0];
+        float a[BK / 4][TM], b[BK / 4][TN];
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[kk][i] = as[(kk * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[kk][j] = bs[(kk * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // fragment burst stays ahead of the MFMA chain
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct TapCfg { int bm, bn; };
+static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}};
+
+static int tap_pick(const IgemmParams& prm) {
+    int best = 0;
+    double best_w = 1e300;
+    for (int i = 0; i < 5; ++i) {
+        const double tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
+        const double tn = (double)(((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn);
+        double w = tm * kTapCfgs[i].bm * tn * kTapCfgs[i].bn;
+        const double blocks = tm * tn;
+        if (blocks < 512) w *= (512.0 / (blocks < 1 ? 1 : blocks)) > 4.0 ? 4.0 : (512.0 / blocks);
+        if (w < best_w * 0.999) { best_w = w; best = i; }
+    }
+    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % 5;
+    return best;
+}
+
+bool igemm_tap_applicable(const IgemmParams& prm) {
+    if (getenv("ZSV_NO_TAP")) return false;
+    return prm.gC >= 16 && prm.taps <= 31 && prm.K > 0;
+}
+
+static inline void tap_layout(const IgemmParams& prm, int& cfg, int& tiles_m, int& Mp, int& nblk, int& Cpad) {
+    cfg = tap_pick(prm);
+    tiles_m = (prm.M + kTapCfgs[cfg].bm - 1) / kTapCfgs[cfg].bm;
+    Mp = tiles_m * kTapCfgs[cfg].bm;
+    nblk = (prm.gC + 15) / 16;
+    Cpad = nblk * 16;
+}
+
+size_t igemm_tap_workspace_bytes(const IgemmParams& prm) {
+    int cfg, tiles_m, Mp, nblk, Cpad;
+    tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
+    return (size_t)prm.taps * Cpad * Mp * sizeof(float);
+}
+
+template <int TM, int TN, int WGM, int WGN>
+static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, const float* bias, float* C,
+                      int tiles_m, int Mp, int nblk, hipStream_t stream) {
+    constexpr int BN = 16 * TN * WGN;
+    const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN);
+    if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
+    hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp, G,
+                       bias, C, tiles_m, Mp, nblk);
+    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+}
+
+int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
+              const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    int cfg, tiles_m, Mp, nblk, Cpad;
+    tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
+    const size_t need = (size_t)prm.taps * Cpad * Mp * sizeof(float);
+    if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;
+    float* Wp = (float*)workspace;
+    const long total = (long)prm.taps * Cpad * Mp;
+    long pb = (total + 255) / 256;
+    if (pb > 4096) pb = 4096;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)pb), dim3(256), 0, stream, prm, W, Wp, w_m_stride, w_c_stride,
+                       Cpad, Mp, total);
+    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    switch (cfg) {
+        case 0: return tap_launch<9, 2, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        case 1: return tap_launch<4, 4, 2, 2>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        case 2: return tap_launch<5, 2, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        case 3: return tap_launch<4, 2, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        default: return tap_launch<3, 4, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+    }
+}
+
+}  // namespace zsv

@@ -120,9 +120,11 @@ class _Conv3d(Function):
         lib = _lib.load()
         timer = KERNEL_TIMER
         with torch.cuda.device(x.device):
+            nbytes = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+            ws = _workspace(nbytes, x.device)
             ev = timer.start() if (timer is not None and timer.wants("conv_fwd", d)) else None
             _lib.check(lib.zsv_conv3d_fwd(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
-                                          1 if relu else 0, _stream()), "zsv_conv3d_fwd")
+                                          1 if relu else 0, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd")
             if ev is not None:
                 timer.stop(ev)
         ctx.desc = d
@@ -146,8 +148,10 @@ class _Conv3d(Function):
                 dy = g
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _stream()),
-                           "zsv_conv3d_dgrad")
+                nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
+                ws = _workspace(nbytes, dy.device)
+                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws),
+                                                nbytes, _stream()), "zsv_conv3d_dgrad")
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
@@ -421,9 +425,12 @@ class _Linear(Function):
         if int(weight.shape[1]) != fin:
             raise RuntimeError("linear: in_features mismatch")
         y = torch.empty((rows, fout), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        nbytes = lib.zsv_linear_fwd_workspace_bytes(rows, fin, fout)
+        ws = _workspace(nbytes, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(_lib.load().zsv_linear_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), rows, fin,
-                                                  fout, 1 if relu else 0, _stream()), "zsv_linear_fwd")
+            _lib.check(lib.zsv_linear_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(), rows, fin,
+                                          fout, 1 if relu else 0, _ptr(ws), nbytes, _stream()), "zsv_linear_fwd")
         ctx.dims = (rows, fin, fout)
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
@@ -445,8 +452,10 @@ class _Linear(Function):
                 dy = g
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
+                nbytes = lib.zsv_linear_dgrad_workspace_bytes(rows, fin, fout)
+                ws = _workspace(nbytes, dy.device)
                 _lib.check(lib.zsv_linear_dgrad(dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), rows, fin, fout,
-                                                _stream()), "zsv_linear_dgrad")
+                                                _ptr(ws), nbytes, _stream()), "zsv_linear_dgrad")
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
                 nbytes = lib.zsv_linear_wgrad_workspace_bytes(rows, fin, fout)
