@@ -28,6 +28,7 @@ struct IgemmParams {
     int k0T, k0H, k0W, tsT, tsH, tsW, kH, kW;
     unsigned g_bytes, a_bytes;     // buffer sizes for the hardware range check
     int relu;
+    int debug;      // timing experiments only (ZSV_CONV_DEBUG): 1 skip global loads, 2 skip LDS stores, 4 skip barrier
 };
 
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, cons
         const int c = (int)(rc % Cpad);
         const int tap = (int)(rc / Cpad);
         float v = 0.f;
-        if (m < prm.M && c < prm.gC) {
+        if (m < prm.M && c < prm.gC && tap < prm.taps) {
             const int jt = tap / prm.nHW;
             const int r = tap - jt * prm.nHW;
             const int jh = r / prm.nW;
@@ -47,19 +47,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, cons
     }
 }
 
-template <int TM, int TN, int WGM, int WGN>
+// NB = 16-channel blocks per K-chunk (BK = 16*NB rows between two barriers)
+template <int TM, int TN, int WGM, int WGN, int NB>
 __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const float* __restrict__ Wp,
                                                        const float* __restrict__ G, const float* __restrict__ bias,
                                                        float* __restrict__ C, int tiles_m, int Mp, int nblk) {
     constexpr int BM = 16 * TM * WGM;
     constexpr int BN = 16 * TN * WGN;
-    constexpr int BK = 16;
+    constexpr int BK = 16 * NB;
     constexpr int LDA = LdPad<BM>::value;
     constexpr int LDB = LdPad<BN>::value;
     constexpr int NT = 256;
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     static_assert(BN == 64 || BN == 128 || BN == 256, "BN must divide the workgroup");
     static_assert(BM % 4 == 0 && LDA % 4 == 0, "16-B weight stores");
+    static_assert(16 % (NT / BN) == 0, "a staging pass never straddles two channel blocks");
     constexpr int BROWS = NT / BN;
     constexpr int BPASS = BK / BROWS;
     constexpr int AQ = BM / 4;                           // float4 per k-row of the weight panel
@@ -136,24 +138,36 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const fl
     float breg[BPASS];
     f32x4 areg[AVPASS];       // native vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
 
-    auto load_chunk = [&](int chunk, int tap, int cb) {
-        const int toff = sgpr(tapoff[tap]);
-        const unsigned ok = (vmask >> tap) & 1u;
-        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);       // padded tap -> 0xFFFFFFFF -> 0.0f
-        const int ci0 = cb * BK;
-        if (ci0 + BK <= prm.gC) {
+    const int nblocks = (prm.K > 0) ? prm.taps * nblk : 0;      // 16-channel blocks in (tap, channel) order
+    const int nchunks = (nblocks + NB - 1) / NB;
+
+    // block index -> (tap, channel block); the walk stays in SGPRs
+    int ld_tap = 0, ld_cb = 0;
+    auto load_chunk = [&](int chunk) {
 #pragma unroll
-            for (int j = 0; j < BPASS; ++j) {
-                const int ci = ci0 + brow0 + BROWS * j;
-                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)voff, ci * ch_bytes, 0));
-            }
-        } else {                                           // last channel block of a tap: rows >= gC are zero
+        for (int blk = 0; blk < NB; ++blk) {
+            constexpr int JB = 16 / BROWS;                     // staging passes per 16-row block
+            const bool live = (chunk * NB + blk) < nblocks;    // a trailing half-chunk is zero
+            const int tap = live ? ld_tap : 0;
+            const int toff = sgpr(tapoff[tap]);
+            const unsigned ok = live ? ((vmask >> tap) & 1u) : 0u;
+            const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);   // padded tap -> 0xFFFFFFFF -> 0.0f
+            const int ci0 = ld_cb * 16;
+            if (ci0 + 16 <= prm.gC) {
 #pragma unroll
-            for (int j = 0; j < BPASS; ++j) {
-                const int ci = ci0 + brow0 + BROWS * j;
-                const unsigned v = ci < prm.gC ? voff : OOB;
-                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0));
+                for (int j = 0; j < JB; ++j) {
+                    const int ci = ci0 + brow0 + BROWS * j;
+                    breg[blk * JB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)voff, ci * ch_bytes, 0));
+                }
+            } else {                                           // last channel block of a tap: rows >= gC are zero
+#pragma unroll
+                for (int j = 0; j < JB; ++j) {
+                    const int ci = ci0 + brow0 + BROWS * j;
+                    const unsigned v = ci < prm.gC ? voff : OOB;
+                    breg[blk * JB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0));
+                }
             }
+            if (live) { if (++ld_cb == nblk) { ld_cb = 0; ++ld_tap; } }
         }
 #pragma unroll
         for (int j = 0; j < AVPASS; ++j)
@@ -173,45 +187,55 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const fl
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = (prm.K > 0) ? prm.taps * nblk : 0;
+    // Pipeline (per chunk c, LDS double-buffered, one barrier):
+    //   [regs of chunk c+1 -> LDS]  [global loads of chunk c+2 -> regs]  [MFMAs of chunk c]  barrier
+    // The staged registers were loaded a whole chunk earlier, so their vmcnt wait is free and
+    // nothing is outstanding when a wave reaches the barrier.
     __syncthreads();                      // tapoff visible
     if (nchunks > 0) {
-        load_chunk(0, 0, 0);
+        load_chunk(0);
         store_chunk(0);
+        if (nchunks > 1) load_chunk(1);
     }
     __syncthreads();
 
     const int frag_row = lane >> 4;
     const int frag_col = lane & 15;
-    int ld_tap = 0, ld_cb = 0;            // (tap, channel block) of the chunk being loaded: walks in SGPRs
+    constexpr int NH = BK / 8;            // 8-row half blocks: fragments are fetched one half ahead
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        const bool more = (ch + 1) < nchunks;
-        if (more) {
-            if (++ld_cb == nblk) { ld_cb = 0; ++ld_tap; }
-            load_chunk(ch + 1, ld_tap, ld_cb);
-        }
+        if (ch + 1 < nchunks && !(prm.debug & 2)) store_chunk(cur ^ 1);
+        if (ch + 2 < nchunks && !(prm.debug & 1)) load_chunk(ch + 2);
+
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
-        float a[BK / 4][TM], b[BK / 4][TN];
+        float a[2][2][TM], b[2][2][TN];
+        auto fetch = [&](int h, int slot) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[kk][i] = as[(kk * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
+                for (int i = 0; i < TM; ++i) a[slot][kk][i] = as[((2 * h + kk) * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[kk][j] = bs[(kk * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+                for (int j = 0; j < TN; ++j) b[slot][kk][j] = bs[((2 * h + kk) * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if (h + 1 < NH) fetch(h + 1, (h + 1) & 1);
+            // the next half's ds_reads are issued ahead of this half's MFMA chain (hipcc otherwise
+            // sinks each read next to its first use and waits lgkmcnt(0) every few MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h & 1][kk][i], b[h & 1][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);      // fragment burst stays ahead of the MFMA chain
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-        }
-        if (more) store_chunk(cur ^ 1);
-        __syncthreads();
+        if (!(prm.debug & 4)) __syncthreads();
     }
 
     store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
@@ -252,7 +276,7 @@ static inline void tap_layout(const IgemmParams& prm, int& cfg, int& tiles_m, in
 size_t igemm_tap_workspace_bytes(const IgemmParams& prm) {
     int cfg, tiles_m, Mp, nblk, Cpad;
     tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
-    return (size_t)prm.taps * Cpad * Mp * sizeof(float);
+    return ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);      // +16 rows: trailing half-chunk reads
 }
 
 template <int TM, int TN, int WGM, int WGN>
@@ -261,20 +285,28 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     constexpr int BN = 16 * TN * WGN;
     const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
-    hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp, G,
-                       bias, C, tiles_m, Mp, nblk);
+    int nb = 1;
+    if (const char* e = getenv("ZSV_CONV_NB")) nb = atoi(e);
+    if (nb == 2)
+        hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp,
+                           G, bias, C, tiles_m, Mp, nblk);
+    else
+        hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp,
+                           G, bias, C, tiles_m, Mp, nblk);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
-int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
+int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c_stride, const float* G,
               const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     int cfg, tiles_m, Mp, nblk, Cpad;
-    tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
-    const size_t need = (size_t)prm.taps * Cpad * Mp * sizeof(float);
+    tap_layout(prm_in, cfg, tiles_m, Mp, nblk, Cpad);
+    IgemmParams prm = prm_in;
+    if (const char* e = getenv("ZSV_CONV_DEBUG")) prm.debug = atoi(e);
+    const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;
     float* Wp = (float*)workspace;
-    const long total = (long)prm.taps * Cpad * Mp;
+    const long total = ((long)prm.taps * Cpad + 16) * Mp;           // the 16 extra rows are zero
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)pb), dim3(256), 0, stream, prm, W, Wp, w_m_stride, w_c_stride,
