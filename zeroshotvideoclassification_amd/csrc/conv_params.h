@@ -84,5 +84,8 @@ size_t igemm_tap_workspace_bytes(const IgemmParams& prm);
 int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
               const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int conv_check(const zsv_conv_desc* d);
+size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d);
+int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace zsv

@@ -4,141 +4,196 @@
 // (resnet.py:23-30,40-52,63-70,170,181,184,270; network.py:102-117) and, with S = 1,
 // the weight gradient of nn.Linear (network.py:611-616,120,132).
 //
-//   dW[co][k] = sum_p dY[co][p] * Xcol[k][p],   k = (ci, kt, kh, kw), p = (n, to, ho, wo)
+//   dW[co][ci][tap] = sum_p dY[co][p] * X[ci][p shifted by tap],   p = (n, to, ho, wo)
 //
-// GEMM with the reduction over output voxels p (up to 1.1 M for layer1) and a small
-// output (Cout x Cin*taps).  MI355X mapping:
-//   * fp32 matrix core v_mfma_f32_16x16x4_f32 (bit-exact fp32), rows = Cout, columns = k;
+// A GEMM whose reduction runs over output voxels p (1.1 M for layer1) and whose output
+// (Cout x Cin*taps) is small.  MI355X mapping:
+//   * fp32 matrix core v_mfma_f32_16x16x4_f32 (bit-exact fp32); rows = Cout, columns = k';
+//   * columns are ordered tap-major, k' = tap * Cpad + ci (Cpad = Cin rounded up to 16), so a
+//     16-column block shares one tap: a lane evaluates the padding test once per block and
+//     chunk, the 16 channels of the block go into the buffer load's scalar offset;  voxel ->
+//     (n, t, h, w) uses multiply-high "magic" division (3 VALU per divide);
 //   * the voxel range is cut into `slices` contiguous ranges (grid.y) so that a launch has
-//     >= ~1k workgroups even when the output has a handful of tiles; every slice writes
-//     its partial slab to the caller's workspace and a second kernel adds the slabs in
-//     slice order -> bitwise reproducible, no float atomics;
-//   * both operands are staged voxel-contiguous: dY rows are read straight along the
-//     contiguous S axis, Xcol rows are gathered on the fly (same per-voxel base offset +
-//     padding-mask scheme as the forward kernel), 32 voxels per chunk;
-//   * LDS images As[BM][LDK], Bs[BN][LDK] with LDK = 34 (== 2 mod 32): the MFMA operand
-//     fetch (16 rows x 2 voxels per 32-lane group) and the staging stores are both
-//     bank-conflict free.
+//     ~1.5k workgroups although the output has a handful of tiles; every slice writes a
+//     partial slab to the caller's workspace and a second kernel adds the slabs in slice
+//     order while un-permuting k' -> (ci, tap): bitwise reproducible, no float atomics;
+//   * dY rows are contiguous along the voxel axis: 16-B loads when S % 4 == 0;
+//   * 32 voxels per chunk; LDS images As[BM][34], Bs[BN][34] (34 == 2 mod 32): the MFMA
+//     operand fetch (16 rows x 2 voxels per 32-lane group) and the staging stores are both
+//     bank-conflict free;  pipeline per chunk c: [regs of c+1 -> LDS][loads of c+2 -> regs]
+//     [MFMAs of c, fragments fetched one 8-voxel group ahead] barrier.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "zsv_hip.h"
-#include "zsv_common.h"
+#include <stdlib.h>
+#include "conv_params.h"
 
 namespace zsv {
 
-int conv_check(const zsv_conv_desc* d);   // conv_igemm.hip
+struct Magic { unsigned mul, shift; };     // q = (umulhi(p, mul) + p) >> shift, exact for p < 2^31
+static Magic make_magic(unsigned d) {
+    Magic m;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    m.shift = s;
+    m.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);     // ceil(2^(32+s)/d) - 2^32
+    return m;
+}
+__device__ __forceinline__ unsigned mdiv(unsigned p, Magic m) { return (__umulhi(p, m.mul) + p) >> m.shift; }
 
 struct WgradParams {
-    int M;            // Cout
-    int K;            // Cin * taps
-    int P;            // N * oS voxels
-    int taps, kHW, kW, kH, kT;
-    int oS, oHW, oW;  // dY geometry
-    int gC, gT, gH, gW, gS, gHW;   // x geometry
+    int M;                  // Cout
+    int Cin, Cpad, nblk;    // channels, padded to 16, 16-channel blocks per tap
+    int taps, kHW, kW;
+    int Kp;                 // taps * Cpad: slab row length
+    int P;                  // N * oS voxels
+    int oS, oHW, oW;        // dY geometry
+    Magic m_oS, m_oHW, m_oW;
+    int gT, gH, gW, gS, gHW, gCS;    // x geometry (gCS = Cin * gS)
     int sT, sH, sW, pT, pH, pW;
-    int chunks_per_slice;          // 32-voxel chunks handled by one slice
-    unsigned x_bytes, dy_bytes;    // buffer sizes for the hardware range check
+    int chunks_per_slice;   // 32-voxel chunks handled by one slice
+    unsigned x_bytes, dy_bytes;
 };
 
-template <int TM, int TN, int WGM, int WGN>
+template <int TM, int TN, int WGM, int WGN, bool AV4>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const float* __restrict__ X,
                                                          const float* __restrict__ DY,
-                                                         float* __restrict__ OUT, int tiles_m) {
+                                                         float* __restrict__ OUT, int tiles_m, int tiles_mn) {
     constexpr int BM = 16 * TM * WGM;
     constexpr int BN = 16 * TN * WGN;
     constexpr int BP = 32;                 // voxels per chunk
     constexpr int LDK = BP + 2;
-    constexpr int RPP = 256 / BP;          // rows per staging pass (8)
-    constexpr int APASS = BM / RPP;
-    constexpr int BPASS = BN / RPP;
+    constexpr int NBLK = BN / 16;          // 16-column blocks of this tile
+    constexpr int BPASS = BN / 8;          // rows staged per thread (8 rows per pass: 256 threads / 32 voxels)
+    constexpr int APASS = AV4 ? (BM + 31) / 32 : BM / 8;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(WGM * WGN == 4, "4 waves");
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of 8");
+    static_assert(BM % 8 == 0, "tile rows must be a multiple of 8");
 
-    __shared__ float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ float Bs[2][BN * LDK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = sgpr(tid >> 6);
     const int wm0 = (wave / WGN) * (16 * TM);
     const int wn0 = (wave % WGN) * (16 * TN);
-    const int m0 = (blockIdx.x % tiles_m) * BM;
-    const int n0 = (blockIdx.x / tiles_m) * BN;
-    const int slice = blockIdx.y;
+    // 1-D grid, XCD-aware: the tiles of one slice (same dY rows, same x voxels) run on one XCD
+    const int lin = xcd_tile(gridDim.x, blockIdx.x);
+    const int tile = lin % tiles_mn;
+    const int slice = lin / tiles_mn;
+    const int m0 = (tile % tiles_m) * BM;
+    const int n0 = (tile / tiles_m) * BN;
 
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, prm.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY), 0, prm.dy_bytes, 0x00020000);
 
-    const int pcol = tid % BP;
-    const int prow0 = tid / BP;
-
-    // the k-rows (and dY rows) a thread stages are the same in every chunk: decode them once
-    int goff[BPASS];        // byte offset of row k inside the gathered tensor (-1: k >= K)
-    int gsel[BPASS];        // packed mask shifts  kw | (8+kh)<<8 | (16+kt)<<16
+    // ---- the tile's 16-column blocks: tap (kt, kh, kw) and first channel, all wave-uniform ----
+    int b_kt[NBLK], b_kh[NBLK], b_kw[NBLK], b_ci0[NBLK];
+    bool has_tail = false;
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-        const int k = n0 + prow0 + RPP * j;
-        goff[j] = 0;
-        gsel[j] = 31 | (31 << 8) | (31 << 16);
-        if (k < prm.K) {
-            const int c = k / prm.taps;
-            const int tap = k - c * prm.taps;
-            const int kt = tap / prm.kHW;
-            const int rr = tap - kt * prm.kHW;
-            const int kh = rr / prm.kW;
-            const int kw = rr - kh * prm.kW;
-            goff[j] = 4 * (c * prm.gS + kt * prm.gHW + kh * prm.gW + kw);
-            gsel[j] = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
-        }
+    for (int b = 0; b < NBLK; ++b) {
+        const int blk = n0 / 16 + b;
+        int tap = blk / prm.nblk;
+        const int cb = blk - tap * prm.nblk;
+        const bool live = tap < prm.taps;
+        tap = live ? tap : 0;
+        const int kt = tap / prm.kHW;
+        const int r = tap - kt * prm.kHW;
+        const int kh = r / prm.kW;
+        b_kt[b] = kt; b_kh[b] = kh; b_kw[b] = r - kh * prm.kW;
+        b_ci0[b] = live ? cb * 16 : prm.Cin;            // dead block: every row is beyond Cin
+        has_tail = has_tail || (b_ci0[b] + 16 > prm.Cin);
     }
+
+    // gather lanes: voxel column pcol, two rows per wave (row parity = half of the wave)
+    const int pcol = tid & (BP - 1);
+    const int half = (tid >> 5) & 1;
+    // dY lanes (AV4): 4 consecutive voxels, 32 rows per pass
+    const int aq = tid & 7, arow = tid >> 3;
 
     const int chunk_begin = slice * prm.chunks_per_slice;
     int chunk_end = chunk_begin + prm.chunks_per_slice;
     const int total_chunks = (prm.P + BP - 1) / BP;
     if (chunk_end > total_chunks) chunk_end = total_chunks;
 
-    float areg[APASS], breg[BPASS];
+    float breg[BPASS];
+    f32x4 areg4[AV4 ? APASS : 1];
+    float areg[AV4 ? 1 : APASS];
+    const int ch_bytes = 4 * prm.gS;
+    const int row_bytes = 4 * prm.oS;
 
     auto load_chunk = [&](int chunk) {
-        const int p = chunk * BP + pcol;
-        unsigned dy_base = 0xFFFFFFFFu;
-        int x_base = 0;
-        unsigned vmask = 0;
-        if (p < prm.P) {
-            const int n = p / prm.oS;
-            int r = p - n * prm.oS;
-            dy_base = 4u * (unsigned)(n * prm.M * prm.oS + r);
-            const int ot = r / prm.oHW;
-            r -= ot * prm.oHW;
-            const int oh = r / prm.oW;
-            const int ow = r - oh * prm.oW;
-            const int t0 = ot * prm.sT - prm.pT, h0 = oh * prm.sH - prm.pH, w0 = ow * prm.sW - prm.pW;
-            x_base = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
-            for (int k = 0; k < prm.kW; ++k) vmask |= ((unsigned)(w0 + k) < (unsigned)prm.gW) << k;
-            for (int k = 0; k < prm.kH; ++k) vmask |= ((unsigned)(h0 + k) < (unsigned)prm.gH) << (8 + k);
-            for (int k = 0; k < prm.kT; ++k) vmask |= ((unsigned)(t0 + k) < (unsigned)prm.gT) << (16 + k);
-        }
-        const unsigned row_bytes = 4u * (unsigned)prm.oS;
+        // ---- gathered operand --------------------------------------------------------------
+        const unsigned p = (unsigned)(chunk * BP + pcol);
+        const bool pv = p < (unsigned)prm.P;
+        const unsigned n = mdiv(p, prm.m_oS);
+        const unsigned r0 = p - n * prm.oS;
+        const unsigned ot = mdiv(r0, prm.m_oHW);
+        const unsigned r1 = r0 - ot * prm.oHW;
+        const unsigned oh = mdiv(r1, prm.m_oW);
+        const unsigned ow = r1 - oh * prm.oW;
+        const int t0 = (int)ot * prm.sT - prm.pT, h0 = (int)oh * prm.sH - prm.pH, w0 = (int)ow * prm.sW - prm.pW;
+        const int xb = 4 * ((int)n * prm.gCS + t0 * prm.gHW + h0 * prm.gW + w0) + half * ch_bytes;
 #pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            const int row = m0 + prow0 + RPP * j;
-            // rows >= M land beyond the buffer only for the last clip; mask them explicitly
-            const unsigned off = (row < prm.M) ? dy_base + (unsigned)row * row_bytes : 0xFFFFFFFFu;
-            areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)(off | (dy_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u)), 0, 0));
-        }
+        for (int b = 0; b < NBLK; ++b) {
+            const bool ok = pv && (unsigned)(t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(h0 + b_kh[b]) < (unsigned)prm.gH &&
+                            (unsigned)(w0 + b_kw[b]) < (unsigned)prm.gW;
+            const unsigned voff = ok ? (unsigned)(xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
+            // rows of block b handled by this thread: ci0 + 2*wave + half + 8*jj, jj = 0,1
 #pragma unroll
-        for (int j = 0; j < BPASS; ++j) {
-            const int sh = gsel[j];
-            const unsigned ok = (vmask >> (sh & 31)) & (vmask >> ((sh >> 8) & 31)) & (vmask >> ((sh >> 16) & 31)) & 1u;
-            const unsigned off = (unsigned)(x_base + goff[j]) | (ok - 1u);
-            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)off, 0, 0));
+            for (int jj = 0; jj < 2; ++jj) {
+                const int ci_u = b_ci0[b] + 2 * wave + 8 * jj;          // wave-uniform part
+                unsigned v = voff;
+                int soff = ci_u * ch_bytes;
+                if (has_tail) {
+                    if (ci_u + half >= prm.Cin) v = OOB;
+                    if (ci_u >= prm.Cin) soff = 0;
+                }
+                breg[2 * b + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)v, soff, 0));
+            }
+        }
+        // ---- dY operand ----------------------------------------------------------------------
+        if (AV4) {
+            // 4 voxels of one clip (oS % 4 == 0); clamp instead of masking: rows >= M are never
+            // stored, voxels >= P meet zeros from the gathered operand
+            unsigned p4 = (unsigned)(chunk * BP + 4 * aq);
+            if (p4 + 4 > (unsigned)prm.P) p4 = (unsigned)prm.P - 4;
+            const unsigned n4 = mdiv(p4, prm.m_oS);
+            const float* base = DY + (size_t)n4 * prm.M * prm.oS + (p4 - n4 * prm.oS);
+#pragma unroll
+            for (int j = 0; j < APASS; ++j) {
+                int row = m0 + (arow + 32 * j) % BM;
+                row = row < prm.M ? row : prm.M - 1;
+                areg4[j] = *reinterpret_cast<const f32x4*>(base + (size_t)row * prm.oS);
+            }
+        } else {
+            const unsigned dyb = pv ? 4u * (n * (unsigned)prm.M * (unsigned)prm.oS + r0) + (unsigned)(half * row_bytes) : OOB;
+#pragma unroll
+            for (int j = 0; j < APASS; ++j) {
+                const int row_u = m0 + 2 * wave + 8 * j;              // wave-uniform part of the row
+                unsigned v = (row_u + half < prm.M) ? dyb : OOB;
+                areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)v, row_u < prm.M ? row_u * row_bytes : 0, 0));
+            }
         }
     };
+
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < APASS; ++j) As[buf][(prow0 + RPP * j) * LDK + pcol] = areg[j];
+        for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-        for (int j = 0; j < BPASS; ++j) Bs[buf][(prow0 + RPP * j) * LDK + pcol] = breg[j];
+            for (int jj = 0; jj < 2; ++jj)
+                Bs[buf][(16 * b + 2 * wave + half + 8 * jj) * LDK + pcol] = breg[2 * b + jj];
+        if (AV4) {
+#pragma unroll
+            for (int j = 0; j < APASS; ++j) {
+                float* dst = &As[buf][((arow + 32 * j) % BM) * LDK + 4 * aq];      // 8-B aligned (LDK even)
+                *reinterpret_cast<float2*>(dst) = make_float2(areg4[j][0], areg4[j][1]);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(areg4[j][2], areg4[j][3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < APASS; ++j) As[buf][(2 * wave + half + 8 * j) * LDK + pcol] = areg[j];
+        }
     };
 
     f32x4 acc[TM][TN];
@@ -150,84 +205,108 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
     if (chunk_begin < chunk_end) {
         load_chunk(chunk_begin);
         store_chunk(0);
+        if (chunk_begin + 1 < chunk_end) load_chunk(chunk_begin + 1);
     }
     __syncthreads();
 
     const int frag_k = lane >> 4;
     const int frag_r = lane & 15;
+    constexpr int NG = BP / 8;             // 8-voxel groups per chunk (2 MFMA k-steps each)
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
         const int cur = (ch - chunk_begin) & 1;
-        const bool more = (ch + 1) < chunk_end;
-        if (more) load_chunk(ch + 1);
+        if (ch + 1 < chunk_end) store_chunk(cur ^ 1);
+        if (ch + 2 < chunk_end) load_chunk(ch + 2);
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
+        float a[2][2][TM], b[2][2][TN];
+        auto fetch = [&](int g, int slot) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float a[BP / 8][TM], b[BP / 8][TN];
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int kk = 0; kk < BP / 8; ++kk) {
+                for (int i = 0; i < TM; ++i) a[slot][kk][i] = as[(wm0 + 16 * i + frag_r) * LDK + (2 * g + kk) * 4 + frag_k];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[kk][i] = as[(wm0 + 16 * i + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[kk][j] = bs[(wn0 + 16 * j + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
+                for (int j = 0; j < TN; ++j) b[slot][kk][j] = bs[(wn0 + 16 * j + frag_r) * LDK + (2 * g + kk) * 4 + frag_k];
             }
-            __builtin_amdgcn_sched_barrier(0);      // fragment burst stays ahead of the MFMA chain
+        };
+        fetch(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < BP / 8; ++kk) {
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);      // next group's ds_reads stay ahead of this group's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][kk][i], b[g & 1][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_chunk(cur ^ 1);
         __syncthreads();
     }
 
-    // partial slab of this slice: OUT[slice][m][k]
-    float* out = OUT + (size_t)slice * prm.M * prm.K;
+    // partial slab of this slice: OUT[slice][m][k'] (k' tap-major)
+    float* out = OUT + (size_t)slice * prm.M * prm.Kp;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int k = n0 + wn0 + 16 * j + frag_r;
-        if (k >= prm.K) continue;
+        if (k >= prm.Kp) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm0 + 16 * i + 4 * frag_k + r;
-                if (m < prm.M) out[(size_t)m * prm.K + k] = acc[i][j][r];
+                if (m < prm.M) out[(size_t)m * prm.Kp + k] = acc[i][j][r];
             }
         }
     }
 }
 
-// dw[i] = sum_s slab[s][i]  (slice order -> deterministic)
+// dw[co][ci][tap] = sum_s slab[s][co][tap * Cpad + ci]   (slice order -> deterministic)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                       long n, int slices) {
+                                                       int M, int Cin, int taps, int Cpad, int slices) {
+    const long n = (long)M * Cin * taps;
+    const size_t slab = (size_t)M * taps * Cpad;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const long r = i / taps;
+        const int ci = (int)(r % Cin);
+        const int co = (int)(r / Cin);
+        const float* src = slabs + ((size_t)co * taps + tap) * Cpad + ci;
         float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * n + i];
+        for (int k = 0; k < slices; ++k) s += src[(size_t)k * slab];
         out[i] = s;
     }
 }
 
 struct WgradPlan {
-    int cfg;        // 0: 128x128, 1: 64x128 (small Cout), 2: 144x64
+    int cfg;        // 0: 144x128, 1: 128x128, 2: 64x128, 3: 80x128
+    int bm, bn;
     int tiles_m, tiles_n, slices, chunks_per_slice;
+    int Cpad, nblk, Kp;
 };
 
 static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     WgradPlan pl;
     const int M = d->Cout;
-    const int K = d->Cin * d->kT * d->kH * d->kW;
+    const int taps = d->kT * d->kH * d->kW;
+    pl.nblk = (d->Cin + 15) / 16;
+    pl.Cpad = pl.nblk * 16;
+    pl.Kp = taps * pl.Cpad;
     const long P = (long)d->N * d->To * d->Ho * d->Wo;
-    int bm, bn;
-    if (M <= 64) { pl.cfg = 1; bm = 64; bn = 128; }
-    else if (M % 144 == 0 || (M > 128 && M <= 144)) { pl.cfg = 2; bm = 144; bn = 64; }
-    else { pl.cfg = 0; bm = 128; bn = 128; }
-    pl.tiles_m = (M + bm - 1) / bm;
-    pl.tiles_n = (K + bn - 1) / bn;
+    const int bms[4] = {144, 128, 64, 80};
+    int best = 0;
+    double best_w = 1e300;
+    for (int i = 0; i < 4; ++i) {
+        const double w = (double)((M + bms[i] - 1) / bms[i]) * bms[i];
+        if (w < best_w * 0.999) { best_w = w; best = i; }
+    }
+    if (const char* e = getenv("ZSV_WGRAD_CFG")) best = atoi(e) & 3;
+    pl.cfg = best;
+    pl.bm = bms[best];
+    pl.bn = 128;
+    pl.tiles_m = (M + pl.bm - 1) / pl.bm;
+    pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
     const long chunks = (P + 31) / 32;
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     long slices = (1536 + tiles - 1) / tiles;            // aim at ~6 workgroups per CU
@@ -241,15 +320,24 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     return pl;
 }
 
+template <int TM, int TN, int WGM, int WGN>
+static void wgrad_launch(const WgradParams& p, bool av4, dim3 grid, hipStream_t stream, const float* x, const float* dy,
+                         float* out, int tiles_m, int tiles_mn) {
+    if (av4)
+        hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+}
+
 }  // namespace zsv
 
 using namespace zsv;
 
 extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (d->Cin < 16) return wgrad_generic_workspace_bytes(d);
     const WgradPlan pl = wgrad_plan(d);
-    if (pl.slices <= 1) return 0;
-    return (size_t)pl.slices * d->Cout * d->Cin * d->kT * d->kH * d->kW * sizeof(float);
+    return (size_t)pl.slices * d->Cout * pl.Kp * sizeof(float);
 }
 
 extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -258,40 +346,44 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     if (st) return st;
     if (!x || !dy || !dw) return ZSV_E_NULL;
     hipStream_t stream = (hipStream_t)stream_;
+    if (d->Cin < 16) return wgrad_generic(d, x, dy, dw, workspace, workspace_bytes, stream);
     const WgradPlan pl = wgrad_plan(d);
     const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
-    if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
+    if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
 
     WgradParams p;
     p.M = d->Cout;
+    p.Cin = d->Cin; p.Cpad = pl.Cpad; p.nblk = pl.nblk;
     p.taps = d->kT * d->kH * d->kW;
-    p.K = d->Cin * p.taps;
+    p.kHW = d->kH * d->kW; p.kW = d->kW;
+    p.Kp = pl.Kp;
     p.P = d->N * d->To * d->Ho * d->Wo;
-    p.kHW = d->kH * d->kW; p.kW = d->kW; p.kH = d->kH; p.kT = d->kT;
     p.oS = d->To * d->Ho * d->Wo; p.oHW = d->Ho * d->Wo; p.oW = d->Wo;
-    p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
-    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
+    p.m_oS = make_magic((unsigned)p.oS); p.m_oHW = make_magic((unsigned)p.oHW); p.m_oW = make_magic((unsigned)p.oW);
+    p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
+    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi; p.gCS = d->Cin * p.gS;
     p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
 
-    float* out = pl.slices > 1 ? (float*)workspace : dw;
-    const dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.slices);
+    const bool av4 = (p.oS % 4 == 0) && (p.P >= 4) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+    const int tiles_mn = pl.tiles_m * pl.tiles_n;
+    const dim3 grid((unsigned)(tiles_mn * pl.slices));
+    float* out = (float*)workspace;
     switch (pl.cfg) {
-        case 0: hipLaunchKernelGGL((conv_wgrad_kernel<4, 4, 2, 2>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
-        case 1: hipLaunchKernelGGL((conv_wgrad_kernel<4, 2, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
-        default: hipLaunchKernelGGL((conv_wgrad_kernel<9, 1, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+        case 0: wgrad_launch<9, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        case 1: wgrad_launch<4, 4, 2, 2>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        case 2: wgrad_launch<4, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        default: wgrad_launch<5, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
     }
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    if (pl.slices > 1) {
-        const long n = (long)p.M * p.K;
-        long blocks = (n + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, pl.slices);
-        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    }
-    return ZSV_OK;
+    const long n = (long)p.M * p.Cin * p.taps;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, p.M,
+                       p.Cin, p.taps, pl.Cpad, pl.slices);
+    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
 extern "C" size_t zsv_linear_wgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {

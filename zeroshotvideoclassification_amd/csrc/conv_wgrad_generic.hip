@@ -1,0 +1,271 @@
+// conv_wgrad_generic.hip -- weight gradient, (channel, tap)-ordered columns, for layers whose
+// input has fewer than 16 channels (the 3-channel stems: resnet.py:170,181; network.py:102).
+//
+// Same GEMM, MFMA, slab reduction and LDS images as conv_wgrad.hip, but a column is one
+// (ci, tap) pair in the weight tensor's own order, so every column carries its own tap: the
+// per-voxel padding mask is tested per gathered element.  With 3 input channels the tap-major
+// kernel would pad every tap's channel block from 3 to 16 (5x wasted MFMAs); here K = 147 is
+// padded to 192 at most.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_params.h"
+
+namespace zsv {
+
+struct WgradGenParams {
+    int M;            // Cout
+    int K;            // Cin * taps
+    int P;            // N * oS voxels
+    int taps, kHW, kW, kH, kT;
+    int oS, oHW, oW;  // dY geometry
+    int gC, gT, gH, gW, gS, gHW;   // x geometry
+    int sT, sH, sW, pT, pH, pW;
+    int chunks_per_slice;          // 32-voxel chunks handled by one slice
+    unsigned x_bytes, dy_bytes;    // buffer sizes for the hardware range check
+};
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(WgradGenParams prm, const float* __restrict__ X,
+                                                         const float* __restrict__ DY,
+                                                         float* __restrict__ OUT, int tiles_m) {
+    constexpr int BM = 16 * TM * WGM;
+    constexpr int BN = 16 * TN * WGN;
+    constexpr int BP = 32;                 // voxels per chunk
+    constexpr int LDK = BP + 2;
+    constexpr int RPP = 256 / BP;          // rows per staging pass (8)
+    constexpr int APASS = BM / RPP;
+    constexpr int BPASS = BN / RPP;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of 8");
+
+    __shared__ float As[2][BM * LDK];
+    __shared__ float Bs[2][BN * LDK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave / WGN) * (16 * TM);
+    const int wn0 = (wave % WGN) * (16 * TN);
+    const int m0 = (blockIdx.x % tiles_m) * BM;
+    const int n0 = (blockIdx.x / tiles_m) * BN;
+    const int slice = blockIdx.y;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, prm.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY), 0, prm.dy_bytes, 0x00020000);
+
+    const int pcol = tid % BP;
+    const int prow0 = tid / BP;
+
+    // the k-rows (and dY rows) a thread stages are the same in every chunk: decode them once
+    int goff[BPASS];        // byte offset of row k inside the gathered tensor (-1: k >= K)
+    int gsel[BPASS];        // packed mask shifts  kw | (8+kh)<<8 | (16+kt)<<16
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+        const int k = n0 + prow0 + RPP * j;
+        goff[j] = 0;
+        gsel[j] = 31 | (31 << 8) | (31 << 16);
+        if (k < prm.K) {
+            const int c = k / prm.taps;
+            const int tap = k - c * prm.taps;
+            const int kt = tap / prm.kHW;
+            const int rr = tap - kt * prm.kHW;
+            const int kh = rr / prm.kW;
+            const int kw = rr - kh * prm.kW;
+            goff[j] = 4 * (c * prm.gS + kt * prm.gHW + kh * prm.gW + kw);
+            gsel[j] = kw | ((8 + kh) << 8) | ((16 + kt) << 16);
+        }
+    }
+
+    const int chunk_begin = slice * prm.chunks_per_slice;
+    int chunk_end = chunk_begin + prm.chunks_per_slice;
+    const int total_chunks = (prm.P + BP - 1) / BP;
+    if (chunk_end > total_chunks) chunk_end = total_chunks;
+
+    float areg[APASS], breg[BPASS];
+
+    auto load_chunk = [&](int chunk) {
+        const int p = chunk * BP + pcol;
+        unsigned dy_base = 0xFFFFFFFFu;
+        int x_base = 0;
+        unsigned vmask = 0;
+        if (p < prm.P) {
+            const int n = p / prm.oS;
+            int r = p - n * prm.oS;
+            dy_base = 4u * (unsigned)(n * prm.M * prm.oS + r);
+            const int ot = r / prm.oHW;
+            r -= ot * prm.oHW;
+            const int oh = r / prm.oW;
+            const int ow = r - oh * prm.oW;
+            const int t0 = ot * prm.sT - prm.pT, h0 = oh * prm.sH - prm.pH, w0 = ow * prm.sW - prm.pW;
+            x_base = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
+            for (int k = 0; k < prm.kW; ++k) vmask |= ((unsigned)(w0 + k) < (unsigned)prm.gW) << k;
+            for (int k = 0; k < prm.kH; ++k) vmask |= ((unsigned)(h0 + k) < (unsigned)prm.gH) << (8 + k);
+            for (int k = 0; k < prm.kT; ++k) vmask |= ((unsigned)(t0 + k) < (unsigned)prm.gT) << (16 + k);
+        }
+        const unsigned row_bytes = 4u * (unsigned)prm.oS;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int row = m0 + prow0 + RPP * j;
+            // rows >= M land beyond the buffer only for the last clip; mask them explicitly
+            const unsigned off = (row < prm.M) ? dy_base + (unsigned)row * row_bytes : 0xFFFFFFFFu;
+            areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)(off | (dy_base == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u)), 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) {
+            const int sh = gsel[j];
+            const unsigned ok = (vmask >> (sh & 31)) & (vmask >> ((sh >> 8) & 31)) & (vmask >> ((sh >> 16) & 31)) & 1u;
+            const unsigned off = (unsigned)(x_base + goff[j]) | (ok - 1u);
+            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)off, 0, 0));
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) As[buf][(prow0 + RPP * j) * LDK + pcol] = areg[j];
+#pragma unroll
+        for (int j = 0; j < BPASS; ++j) Bs[buf][(prow0 + RPP * j) * LDK + pcol] = breg[j];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (chunk_begin < chunk_end) {
+        load_chunk(chunk_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    const int frag_k = lane >> 4;
+    const int frag_r = lane & 15;
+    for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+        const int cur = (ch - chunk_begin) & 1;
+        const bool more = (ch + 1) < chunk_end;
+        if (more) load_chunk(ch + 1);
+        const float* as = &As[cur][0];
+        const float* bs = &Bs[cur][0];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float a[BP / 8][TM], b[BP / 8][TN];
+#pragma unroll
+            for (int kk = 0; kk < BP / 8; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[kk][i] = as[(wm0 + 16 * i + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[kk][j] = bs[(wn0 + 16 * j + frag_r) * LDK + (half * (BP / 8) + kk) * 4 + frag_k];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // fragment burst stays ahead of the MFMA chain
+#pragma unroll
+            for (int kk = 0; kk < BP / 8; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial slab of this slice: OUT[slice][m][k]
+    float* out = OUT + (size_t)slice * prm.M * prm.K;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn0 + 16 * j + frag_r;
+        if (k >= prm.K) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm0 + 16 * i + 4 * frag_k + r;
+                if (m < prm.M) out[(size_t)m * prm.K + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// dw[i] = sum_s slab[s][i]  (slice order -> deterministic)
+__global__ __launch_bounds__(256) void slab_sum_generic_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                       long n, int slices) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+struct WgradGenPlan {
+    int cfg;        // 0: 128x128, 1: 64x128 (small Cout), 2: 144x64
+    int tiles_m, tiles_n, slices, chunks_per_slice;
+};
+
+static WgradGenPlan wgrad_gen_plan(const zsv_conv_desc* d) {
+    WgradGenPlan pl;
+    const int M = d->Cout;
+    const int K = d->Cin * d->kT * d->kH * d->kW;
+    const long P = (long)d->N * d->To * d->Ho * d->Wo;
+    int bm, bn;
+    if (M <= 64) { pl.cfg = 1; bm = 64; bn = 128; }
+    else if (M % 144 == 0 || (M > 128 && M <= 144)) { pl.cfg = 2; bm = 144; bn = 64; }
+    else { pl.cfg = 0; bm = 128; bn = 128; }
+    pl.tiles_m = (M + bm - 1) / bm;
+    pl.tiles_n = (K + bn - 1) / bn;
+    const long chunks = (P + 31) / 32;
+    const long tiles = (long)pl.tiles_m * pl.tiles_n;
+    long slices = (1536 + tiles - 1) / tiles;            // aim at ~6 workgroups per CU
+    long max_slices = (chunks + 15) / 16;                // at least 16 chunks (512 voxels) per slice
+    if (max_slices < 1) max_slices = 1;
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    if (slices > 1024) slices = 1024;
+    pl.chunks_per_slice = (int)((chunks + slices - 1) / slices);
+    pl.slices = (int)((chunks + pl.chunks_per_slice - 1) / pl.chunks_per_slice);
+    return pl;
+}
+
+
+size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d) {
+    const WgradGenPlan pl = wgrad_gen_plan(d);
+    if (pl.slices <= 1) return 0;
+    return (size_t)pl.slices * d->Cout * d->Cin * d->kT * d->kH * d->kW * sizeof(float);
+}
+
+int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+    const WgradGenPlan pl = wgrad_gen_plan(d);
+    const size_t need = wgrad_generic_workspace_bytes(d);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
+    WgradGenParams p;
+    p.M = d->Cout;
+    p.taps = d->kT * d->kH * d->kW;
+    p.K = d->Cin * p.taps;
+    p.P = d->N * d->To * d->Ho * d->Wo;
+    p.kHW = d->kH * d->kW; p.kW = d->kW; p.kH = d->kH; p.kT = d->kT;
+    p.oS = d->To * d->Ho * d->Wo; p.oHW = d->Ho * d->Wo; p.oW = d->Wo;
+    p.gC = d->Cin; p.gT = d->Ti; p.gH = d->Hi; p.gW = d->Wi;
+    p.gS = d->Ti * d->Hi * d->Wi; p.gHW = d->Hi * d->Wi;
+    p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+    p.chunks_per_slice = pl.chunks_per_slice;
+    p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
+    p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
+    float* out = pl.slices > 1 ? (float*)workspace : dw;
+    const dim3 grid((unsigned)(pl.tiles_m * pl.tiles_n), (unsigned)pl.slices);
+    switch (pl.cfg) {
+        case 0: hipLaunchKernelGGL((conv_wgrad_generic_kernel<4, 4, 2, 2>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+        case 1: hipLaunchKernelGGL((conv_wgrad_generic_kernel<4, 2, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+        default: hipLaunchKernelGGL((conv_wgrad_generic_kernel<9, 1, 1, 4>), grid, dim3(256), 0, stream, p, x, dy, out, pl.tiles_m); break;
+    }
+    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (pl.slices > 1) {
+        const long n = (long)p.M * p.K;
+        long blocks = (n + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(slab_sum_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, pl.slices);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    }
+    return ZSV_OK;
+}
+
+}  // namespace zsv
