@@ -25,17 +25,22 @@
 
 namespace zsv {
 
-// Wp[(tap * Cpad + c) * Mp + m] = W[m * w_m_stride + c * w_c_stride + tap_full(tap)]  (0 in the padding)
+// Wp[((cb * taps + tap) * 16 + c % 16) * Mp + m] = W[m * w_m_stride + c * w_c_stride + tap_full(tap)], cb = c / 16
+// (0 in the padding)
 __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, const float* __restrict__ W,
                                                            float* __restrict__ Wp, int w_m_stride, int w_c_stride,
                                                            int Cpad, int Mp, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // row = ((channel block * taps) + tap) * 16 + channel-in-block: all taps of a 16-channel
+        // block are consecutive chunks, so the gathered rows stay hot in L1/L2 across the taps
         const int m = (int)(i % Mp);
         const long rc = i / Mp;
-        const int c = (int)(rc % Cpad);
-        const int tap = (int)(rc / Cpad);
+        const int blk = (int)(rc / 16);
+        const int cb = blk / prm.taps;
+        const int tap = blk - cb * prm.taps;
+        const int c = cb * 16 + (int)(rc % 16);
         float v = 0.f;
-        if (m < prm.M && c < prm.gC && tap < prm.taps) {
+        if (m < prm.M && c < prm.gC && cb * 16 < Cpad) {
             const int jt = tap / prm.nHW;
             const int r = tap - jt * prm.nHW;
             const int jh = r / prm.nW;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const fl
     float breg[BPASS];
     f32x4 areg[AVPASS];       // native vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
 
-    const int nblocks = (prm.K > 0) ? prm.taps * nblk : 0;      // 16-channel blocks in (tap, channel) order
+    const int nblocks = (prm.K > 0) ? prm.taps * nblk : 0;      // 16-channel blocks, (channel block, tap) order
     const int nchunks = (nblocks + NB - 1) / NB;
 
     // block index -> (tap, channel block); the walk stays in SGPRs
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const fl
                     breg[blk * JB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0));
                 }
             }
-            if (live) { if (++ld_cb == nblk) { ld_cb = 0; ++ld_tap; } }
+            if (live) { if (++ld_tap == prm.taps) { ld_tap = 0; ++ld_cb; } }
         }
 #pragma unroll
         for (int j = 0; j < AVPASS; ++j)
@@ -242,6 +247,180 @@ __global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// LDS-DMA variant: the gathered slab and the weight panel go global -> LDS directly
+// (`buffer_load_dword ... lds` per k-row, `global_load_lds_dwordx4` for the panel): no staging
+// VGPRs, no ds_write, so the register budget drops under 128 (4 waves per SIMD) and the only
+// LDS instructions left are the MFMA fragment reads.  The LDS destination of a DMA is
+// wave-uniform base + lane * size, which is exactly a k-row segment of 64 voxels; the panel is
+// written as a linear image of the padded [16][LDA] array (pad slots load a dummy element).
+// One chunk is in flight: issued right after the barrier, awaited (vmcnt(0)) before the next one.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef WAVES_PER_EU
+#define WAVES_PER_EU 4
+#endif
+
+template <int TM, int TN, int WGM, int WGN, int FK>     // FK = MFMA k-steps per fragment burst (1 or 2)
+__global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmParams prm, const float* __restrict__ Wp,
+                                                           const float* __restrict__ G, const float* __restrict__ bias,
+                                                           float* __restrict__ C, int tiles_m, int Mp, int nblk) {
+#if defined(__HIP_DEVICE_COMPILE__)     // (address_space(3) casts: the host pass would drop the stub)
+    constexpr int BM = 16 * TM * WGM;
+    constexpr int BN = 16 * TN * WGN;
+    constexpr int BK = 16;
+    constexpr int LDA = LdPad<BM>::value;
+    constexpr int LDB = LdPad<BN>::value;
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
+    static_assert(BN == 64 || BN == 128 || BN == 256, "a k-row is split into 64-voxel wave segments");
+    constexpr int WPR = BN / 64;                 // waves per k-row
+    constexpr int RPP = 4 / WPR;                 // k-rows per pass
+    constexpr int BPASS = BK / RPP;
+    constexpr int ASLOTS = BK * LDA / 4;         // float4 slots of the padded panel image
+    constexpr int APASS = (ASLOTS + 255) / 256;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    __shared__ int tapoff[32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = sgpr(tid >> 6);
+    const int wm0 = (wave / WGN) * (16 * TM);
+    const int wn0 = (wave % WGN) * (16 * TN);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int m0 = (tile % tiles_m) * BM;
+    const int n0 = (tile / tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, prm.g_bytes, 0x00020000);
+
+    if (tid < prm.taps) {
+        const int jt = tid / prm.nHW;
+        const int r = tid - jt * prm.nHW;
+        const int jh = r / prm.nW;
+        const int jw = r - jh * prm.nW;
+        tapoff[tid] = 4 * prm.dir * (jt * prm.gHW + jh * prm.gW + jw);
+    }
+
+    // ---- this lane's voxel: column (wave % WPR) * 64 + lane of the tile --------------------
+    const int bcol0 = (wave % WPR) * 64;         // wave-uniform
+    const int brow0 = wave / WPR;
+    int base_bytes = 0;
+    unsigned vmask = 0;
+    {
+        const int p = n0 + bcol0 + lane;
+        if (p < prm.P) {
+            const int n = p / prm.cS;
+            int r = p - n * prm.cS;
+            const int ct = r / prm.cHW;
+            r -= ct * prm.cHW;
+            const int ch = r / prm.cW;
+            const int cw = r - ch * prm.cW;
+            const int t0 = ct * prm.gsT + prm.goT, h0 = ch * prm.gsH + prm.goH, w0 = cw * prm.gsW + prm.goW;
+            base_bytes = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
+            unsigned mw = 0, mh = 0, mt = 0;
+            for (int j = 0; j < prm.nW; ++j) mw |= ((unsigned)(w0 + prm.dir * j) < (unsigned)prm.gW) << j;
+            for (int j = 0; j < prm.nH; ++j) mh |= ((unsigned)(h0 + prm.dir * j) < (unsigned)prm.gH) << j;
+            for (int j = 0; j < prm.nT; ++j) mt |= ((unsigned)(t0 + prm.dir * j) < (unsigned)prm.gT) << j;
+            int tap = 0;
+            for (int a = 0; a < prm.nT; ++a)
+                for (int b = 0; b < prm.nH; ++b)
+                    for (int c = 0; c < prm.nW; ++c, ++tap)
+                        vmask |= (((mt >> a) & (mh >> b) & (mw >> c)) & 1u) << tap;
+        }
+    }
+
+    // ---- weight panel: per pass, the source of this lane's float4 slot of the padded image --
+    const float* a_src[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int slot = 64 * (wave + 4 * j) + lane;
+        const int r = (slot / (LDA / 4)) % BK, c4 = slot % (LDA / 4);
+        a_src[j] = Wp + (size_t)r * Mp + m0 + (c4 < BM / 4 ? 4 * c4 : 0);      // pad slots re-read column 0
+    }
+    const size_t a_chunk_stride = (size_t)BK * Mp;
+    const int ch_bytes = 4 * prm.gS;
+
+    const int nchunks = (prm.K > 0) ? prm.taps * nblk : 0;
+    int ld_tap = 0, ld_cb = 0;
+    auto issue_chunk = [&](int chunk, int buf) {
+        const int toff = sgpr(tapoff[ld_tap]);
+        const unsigned ok = (vmask >> ld_tap) & 1u;
+        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);
+        const int ci0 = ld_cb * 16;
+        float* bdst = &Bs[buf][brow0 * LDB + bcol0];
+        if (ci0 + 16 <= prm.gC) {
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                const int ci = ci0 + brow0 + RPP * j;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t)(bdst + RPP * j * LDB), 4, (int)voff, ci * ch_bytes, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BPASS; ++j) {
+                const int ci = ci0 + brow0 + RPP * j;
+                const unsigned v = ci < prm.gC ? voff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t)(bdst + RPP * j * LDB), 4, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            if (64 * (wave + 4 * j) < ASLOTS)          // wave-uniform
+                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride,
+                                                 (lds_ptr_t)(&As[buf][256 * (wave + 4 * j)]), 16, 0, 0);
+        }
+        if (++ld_tap == prm.taps) { ld_tap = 0; ++ld_cb; }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();                      // tapoff visible
+    if (nchunks > 0) issue_chunk(0, 0);
+    __syncthreads();                      // (drains the DMA: vmcnt(0) before the barrier)
+
+    const int frag_row = lane >> 4;
+    const int frag_col = lane & 15;
+    constexpr int NS = (BK / 4) / FK;     // fragment bursts per chunk
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) issue_chunk(ch + 1, cur ^ 1);
+        const float* as = &As[cur][0];
+        const float* bs = &Bs[cur][0];
+        float a[2][FK][TM], b[2][FK][TN];
+        auto fetch = [&](int s_, int slot) {
+#pragma unroll
+            for (int kk = 0; kk < FK; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[slot][kk][i] = as[((FK * s_ + kk) * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[slot][kk][j] = bs[((FK * s_ + kk) * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            if (s_ + 1 < NS) fetch(s_ + 1, (s_ + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < FK; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ & 1][kk][i], b[s_ & 1][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 struct TapCfg { int bm, bn; };
 static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}};
 
@@ -285,9 +464,16 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     constexpr int BN = 16 * TN * WGN;
     const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
-    int nb = 1;
+    int nb = 1, dma = 1;
     if (const char* e = getenv("ZSV_CONV_NB")) nb = atoi(e);
-    if (nb == 2)
+    if (const char* e = getenv("ZSV_CONV_DMA")) dma = atoi(e);
+    if (dma == 1)
+        hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
+                           Wp, G, bias, C, tiles_m, Mp, nblk);
+    else if (dma == 2)
+        hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
+                           Wp, G, bias, C, tiles_m, Mp, nblk);
+    else if (nb == 2)
         hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp,
                            G, bias, C, tiles_m, Mp, nblk);
     else
