@@ -262,20 +262,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
     }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][co][tap * Cpad + ci]   (slice order -> deterministic)
+// dw[co][ci][tap] = sum_s slab[s][co][tap * Cpad + ci]   (slice order -> deterministic).
+// Threads walk the slab order (ci fastest) so the `slices` reads per element are coalesced; the
+// single strided write per element is 1/slices of the traffic.
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        int M, int Cin, int taps, int Cpad, int slices) {
-    const long n = (long)M * Cin * taps;
     const size_t slab = (size_t)M * taps * Cpad;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int tap = (int)(i % taps);
-        const long r = i / taps;
-        const int ci = (int)(r % Cin);
-        const int co = (int)(r / Cin);
-        const float* src = slabs + ((size_t)co * taps + tap) * Cpad + ci;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < slab; j += (size_t)gridDim.x * 256) {
+        const int ci = (int)(j % Cpad);
+        if (ci >= Cin) continue;
+        const size_t r = j / Cpad;
+        const int tap = (int)(r % taps);
+        const int co = (int)(r / taps);
+        const float* src = slabs + j;
         float s = 0.f;
         for (int k = 0; k < slices; ++k) s += src[(size_t)k * slab];
-        out[i] = s;
+        out[((size_t)co * Cin + ci) * taps + tap] = s;
     }
 }
 
@@ -309,12 +311,25 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
     const long chunks = (P + 31) / 32;
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
-    long slices = (1536 + tiles - 1) / tiles;            // aim at ~6 workgroups per CU
+    // one full round of resident workgroups (256 CUs x LDS-limited 2-3 per CU): every workgroup
+    // then runs start to finish concurrently and the slab traffic is minimal
+    const long resident = 256L * (pl.bm == 64 ? 3 : 2);
     long max_slices = (chunks + 15) / 16;                // at least 16 chunks (512 voxels) per slice
     if (max_slices < 1) max_slices = 1;
+    if (max_slices > 1024) max_slices = 1024;
+    // pick the slice count whose workgroup count fills whole rounds best (fewer slices on ties:
+    // less slab traffic)
+    long slices = 1;
+    double best_eff = -1.0;
+    for (long s = 1; s <= max_slices && tiles * s <= 4 * resident + tiles; ++s) {
+        const long wgs = tiles * s;
+        const long rounds = (wgs + resident - 1) / resident;
+        const double eff = (double)wgs / (double)(rounds * resident) - 0.02 * (double)wgs / (double)resident;
+        if (eff > best_eff + 1e-9) { best_eff = eff; slices = s; }
+    }
+    if (const char* e = getenv("ZSV_WGRAD_WGS")) slices = atol(e) / tiles;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
-    if (slices > 1024) slices = 1024;
     pl.chunks_per_slice = (int)((chunks + slices - 1) / slices);
     pl.slices = (int)((chunks + pl.chunks_per_slice - 1) / pl.chunks_per_slice);
     return pl;
@@ -378,9 +393,9 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
         default: wgrad_launch<5, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
     }
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    const long n = (long)p.M * p.Cin * p.taps;
+    const long n = (long)p.M * p.taps * pl.Cpad;
     long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, p.M,
                        p.Cin, p.taps, pl.Cpad, pl.slices);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
