@@ -269,3 +269,25 @@ def test_adam_step_matches_torch():
         opt.step()
         ops.adam_step_(pg, grad.to(DEV), m, v, step, 1e-3)
     close(pg, pr, rtol=1e-6, what="adam")
+
+
+def test_conv3d_split_k_small_grid():
+    # few output tiles + long reduction: the forward / dgrad kernels cut the K range into parts
+    # (partial slabs + ordered reduce); layer4 geometry of R(2+1)D-18 scaled down in N
+    g = torch.Generator().manual_seed(21)
+    for (cin, cout, k, s, p, t, h, w) in [(256, 320, (1, 3, 3), (1, 1, 1), (0, 1, 1), 2, 7, 7),
+                                          (320, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), 2, 7, 7),
+                                          (128, 200, (1, 3, 3), (1, 2, 2), (0, 1, 1), 2, 14, 14)]:
+        x = torch.randn(2, cin, t, h, w, generator=g)
+        wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+        b = torch.randn(cout, generator=g)
+        xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+        yr = F.relu(F.conv3d(xr, wr, br, stride=s, padding=p))
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy.double())
+        xg, wg, bg = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+        yg = ops.conv3d(xg, wg, bg, s, p, relu=True)
+        yg.backward(dy.to(DEV))
+        close(yg, yr, what="split-K fwd")
+        close(xg.grad, xr.grad, what="split-K dgrad")
+        close(wg.grad, wr.grad, what="split-K wgrad")

@@ -81,11 +81,17 @@ const zsv_conv_desc linear_desc(int32_t rows, int32_t in_features, int32_t out_f
 
 }  // namespace
 
+// workspace layout of a tap-kernel call: [packed weights (16-B aligned)] [split-K slabs]
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
     IgemmParams p;
     fwd_params(p, d, 0);
-    return igemm_tap_applicable(p) ? igemm_tap_workspace_bytes(p) : 0;
+    if (!igemm_tap_applicable(p)) return 0;
+    const int ks = igemm_tap_ksplit(p);
+    const size_t out_elems = (size_t)d->N * d->Cout * d->To * d->Ho * d->Wo;
+    return align256(igemm_tap_workspace_bytes(p)) + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
 }
 
 extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -95,24 +101,47 @@ extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const floa
     if (!x || !w || !y) return ZSV_E_NULL;
     IgemmParams p;
     fwd_params(p, d, fuse_relu);
-    if (igemm_tap_applicable(p))
-        return igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, bias, y, workspace, workspace_bytes, (hipStream_t)stream);
+    if (igemm_tap_applicable(p)) {
+        if (workspace_bytes < zsv_conv3d_fwd_workspace_bytes(d) || !workspace) return ZSV_E_WORKSPACE;
+        const int ks = igemm_tap_ksplit(p);
+        const size_t wbytes = align256(igemm_tap_workspace_bytes(p));
+        const long out_elems = (long)d->N * d->Cout * d->To * d->Ho * d->Wo;
+        float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
+        p.ksplit = ks;
+        p.slab_elems = (int)out_elems;
+        st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, bias, y, workspace, wbytes, slabs, (hipStream_t)stream);
+        if (st || ks <= 1) return st;
+        return splitk_reduce(slabs, ks, out_elems, d->Cout, p.oS, bias, fuse_relu ? 1 : 0, y, (hipStream_t)stream);
+    }
     const bool avec = (p.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     return igemm_generic(p, avec, w, x, bias, y, (hipStream_t)stream);
 }
 
-extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
-    if (conv_check(d) != ZSV_OK) return 0;
-    size_t need = 0;
+// one split factor for every residue class of a dgrad call (they share the slabs)
+static int dgrad_plan(const zsv_conv_desc* d, size_t& wbytes) {
     IgemmParams p;
+    int ks = 0;
+    bool all_tap = true;
+    wbytes = 0;
     for (int rt = 0; rt < d->sT; ++rt)
         for (int rh = 0; rh < d->sH; ++rh)
-            for (int rw = 0; rw < d->sW; ++rw)
-                if (dgrad_class_params(p, d, rt, rh, rw) && igemm_tap_applicable(p)) {
-                    const size_t b = igemm_tap_workspace_bytes(p);
-                    if (b > need) need = b;
-                }
-    return need;
+            for (int rw = 0; rw < d->sW; ++rw) {
+                if (!dgrad_class_params(p, d, rt, rh, rw)) continue;
+                if (!igemm_tap_applicable(p)) { all_tap = false; continue; }
+                const size_t b = align256(igemm_tap_workspace_bytes(p));
+                if (b > wbytes) wbytes = b;
+                const int k = igemm_tap_ksplit(p);
+                if (ks == 0 || k < ks) ks = k;
+            }
+    return (all_tap && ks > 1) ? ks : 1;
+}
+
+extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    size_t wbytes;
+    const int ks = dgrad_plan(d, wbytes);
+    const size_t out_elems = (size_t)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
+    return wbytes + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
 }
 
 extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
@@ -120,19 +149,29 @@ extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const f
     int st = conv_check(d);
     if (st) return st;
     if (!dy || !w || !dx) return ZSV_E_NULL;
+    size_t wbytes;
+    const int ks = dgrad_plan(d, wbytes);
+    const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
+    const size_t need = wbytes + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
+    float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
     IgemmParams p;
     // one launch per residue class; the classes reuse the (stream-ordered) weight workspace
     for (int rt = 0; rt < d->sT; ++rt)
         for (int rh = 0; rh < d->sH; ++rh)
             for (int rw = 0; rw < d->sW; ++rw) {
                 if (!dgrad_class_params(p, d, rt, rh, rw)) continue;
-                if (igemm_tap_applicable(p))
-                    st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, workspace_bytes,
+                if (igemm_tap_applicable(p)) {
+                    p.ksplit = ks;
+                    p.slab_elems = (int)out_elems;
+                    st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, wbytes, slabs,
                                    (hipStream_t)stream);
-                else
+                } else {
                     st = igemm_generic(p, false, w, dy, nullptr, dx, (hipStream_t)stream);
+                }
                 if (st) return st;
             }
+    if (ks > 1) return splitk_reduce(slabs, ks, out_elems, d->Cin, p.oS, nullptr, 0, dx, (hipStream_t)stream);
     return ZSV_OK;
 }
 

@@ -28,6 +28,8 @@ struct IgemmParams {
     int k0T, k0H, k0W, tsT, tsH, tsW, kH, kW;
     unsigned g_bytes, a_bytes;     // buffer sizes for the hardware range check
     int relu;
+    int ksplit;     // > 1: the K range is cut into ksplit parts, each writing a partial C slab
+    int slab_elems; // elements of one C slab (= N * M * oS)
     int debug;      // timing experiments only (ZSV_CONV_DEBUG): 1 skip global loads, 2 skip LDS stores, 4 skip barrier
 };
 
@@ -81,8 +83,12 @@ int igemm_generic(const IgemmParams& prm, bool avec, const float* A, const float
                   hipStream_t stream);
 bool igemm_tap_applicable(const IgemmParams& prm);
 size_t igemm_tap_workspace_bytes(const IgemmParams& prm);
+// `slabs` != nullptr with prm.ksplit > 1: partial sums go to slabs[split][...] (reduce afterwards)
 int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
-              const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream);
+              const float* bias, float* C, void* workspace, size_t workspace_bytes, float* slabs, hipStream_t stream);
+int igemm_tap_ksplit(const IgemmParams& prm);     // suggested split of the K range (1 = none)
+int splitk_reduce(const float* slabs, int ksplit, long elems, int M, int oS, const float* bias, int relu, float* C,
+                  hipStream_t stream);
 int conv_check(const zsv_conv_desc* d);
 size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,

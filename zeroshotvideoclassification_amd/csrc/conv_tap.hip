@@ -287,7 +287,10 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     const int wave = sgpr(tid >> 6);
     const int wm0 = (wave / WGN) * (16 * TM);
     const int wn0 = (wave % WGN) * (16 * TN);
-    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int lin = xcd_tile(gridDim.x, blockIdx.x);
+    const int ntiles = gridDim.x / prm.ksplit;
+    const int tile = lin % ntiles;
+    const int split = lin / ntiles;          // which part of the K range (split-K for small grids)
     const int m0 = (tile % tiles_m) * BM;
     const int n0 = (tile / tiles_m) * BN;
 
@@ -340,8 +343,11 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     const size_t a_chunk_stride = (size_t)BK * Mp;
     const int ch_bytes = 4 * prm.gS;
 
-    const int nchunks = (prm.K > 0) ? prm.taps * nblk : 0;
-    int ld_tap = 0, ld_cb = 0;
+    const int nchunks_all = (prm.K > 0) ? prm.taps * nblk : 0;
+    const int per_split = (nchunks_all + prm.ksplit - 1) / prm.ksplit;
+    const int c_begin = split * per_split;
+    const int nchunks = max(0, min(nchunks_all, c_begin + per_split) - c_begin);
+    int ld_cb = c_begin / prm.taps, ld_tap = c_begin - ld_cb * prm.taps;
     auto issue_chunk = [&](int chunk, int buf) {
         const int toff = sgpr(tapoff[ld_tap]);
         const unsigned ok = (vmask >> ld_tap) & 1u;
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
             if (64 * (wave + 4 * j) < ASLOTS)          // wave-uniform
-                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride,
+                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)(c_begin + chunk) * a_chunk_stride,
                                                  (lds_ptr_t)(&As[buf][256 * (wave + 4 * j)]), 16, 0, 0);
         }
         if (++ld_tap == prm.taps) { ld_tap = 0; ++ld_cb; }
@@ -416,8 +422,36 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
         __syncthreads();
     }
 
-    store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
+    if (prm.ksplit > 1) {                    // raw partial sums; bias / ReLU are applied by the slab reduce
+        IgemmParams q = prm;
+        q.relu = 0;
+        store_tiles<TM, TN>(q, acc, m0 + wm0, n0 + wn0, lane, nullptr, C + (size_t)split * prm.slab_elems);
+    } else {
+        store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
+    }
 #endif
+}
+
+// C = sum_s slab[s] (+ bias[m]) (ReLU): fixed order, deterministic
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int ksplit, long elems, int M,
+                                                            int oS, const float* __restrict__ bias, int relu,
+                                                            float* __restrict__ C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < elems; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += slabs[(size_t)s * elems + i];
+        if (bias) v += bias[(i / oS) % M];
+        if (relu) v = fmaxf(v, 0.f);
+        C[i] = v;
+    }
+}
+
+int splitk_reduce(const float* slabs, int ksplit, long elems, int M, int oS, const float* bias, int relu, float* C,
+                  hipStream_t stream) {
+    long blocks = (elems + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, ksplit, elems, M, oS, bias,
+                       relu, C);
+    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,11 +496,12 @@ template <int TM, int TN, int WGM, int WGN>
 static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, const float* bias, float* C,
                       int tiles_m, int Mp, int nblk, hipStream_t stream) {
     constexpr int BN = 16 * TN * WGN;
-    const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN);
+    const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN) * (prm.ksplit > 1 ? prm.ksplit : 1);
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
     int nb = 1, dma = 1;
     if (const char* e = getenv("ZSV_CONV_NB")) nb = atoi(e);
     if (const char* e = getenv("ZSV_CONV_DMA")) dma = atoi(e);
+    if (prm.ksplit > 1 && dma == 0) dma = 1;         // split-K lives in the DMA kernel
     if (dma == 1)
         hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
                            Wp, G, bias, C, tiles_m, Mp, nblk);
@@ -482,12 +517,27 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
+int igemm_tap_ksplit(const IgemmParams& prm) {
+    if (getenv("ZSV_NO_SPLITK")) return 1;
+    int cfg, tiles_m, Mp, nblk, Cpad;
+    tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
+    const long tiles = (long)tiles_m * (((long)prm.P + kTapCfgs[cfg].bn - 1) / kTapCfgs[cfg].bn);
+    const long nchunks = (long)prm.taps * nblk;
+    if (tiles >= 384 || nchunks < 32) return 1;
+    long ks = (768 + tiles - 1) / tiles;                 // aim at ~3 workgroups per CU
+    if (ks > nchunks / 12) ks = nchunks / 12;            // >= 12 chunks per part
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : (int)ks;
+}
+
 int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c_stride, const float* G,
-              const float* bias, float* C, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+              const float* bias, float* C, void* workspace, size_t workspace_bytes, float* slabs, hipStream_t stream) {
     int cfg, tiles_m, Mp, nblk, Cpad;
     tap_layout(prm_in, cfg, tiles_m, Mp, nblk, Cpad);
     IgemmParams prm = prm_in;
     if (const char* e = getenv("ZSV_CONV_DEBUG")) prm.debug = atoi(e);
+    if (prm.ksplit < 1 || !slabs) prm.ksplit = 1;
+    if (prm.ksplit > 1) C = slabs;                       // partial slabs instead of the output tensor
     const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;
