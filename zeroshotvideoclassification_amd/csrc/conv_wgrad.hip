@@ -54,20 +54,24 @@ struct WgradParams {
     unsigned x_bytes, dy_bytes;
 };
 
-template <int TM, int TN, int WGM, int WGN, bool AV4>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const float* __restrict__ X,
+template <int TM, int TN, int WGM, int WGN, bool AV4, int BP>      // BP = voxels per chunk (32 or 16)
+__global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(WgradParams prm, const float* __restrict__ X,
                                                          const float* __restrict__ DY,
                                                          float* __restrict__ OUT, int tiles_m, int tiles_mn) {
     constexpr int BM = 16 * TM * WGM;
     constexpr int BN = 16 * TN * WGN;
-    constexpr int BP = 32;                 // voxels per chunk
     constexpr int LDK = BP + 2;
     constexpr int NBLK = BN / 16;          // 16-column blocks of this tile
-    constexpr int BPASS = BN / 8;          // rows staged per thread (8 rows per pass: 256 threads / 32 voxels)
-    constexpr int APASS = AV4 ? (BM + 31) / 32 : BM / 8;
+    constexpr int RW = 64 / BP;            // rows covered by one wave-instruction (2 or 4)
+    constexpr int RPP = 4 * RW;            // rows per staging pass (8 or 16)
+    constexpr int PB = 16 / RPP;           // passes per 16-row block (2 or 1)
+    constexpr int BPASS = NBLK * PB;       // gathered rows staged per thread
+    constexpr int AQ = BP / 4;             // float4 per dY row (8 or 4)
+    constexpr int ARP = 256 / AQ;          // dY rows per float4 pass (32 or 64)
+    constexpr int APASS = AV4 ? (BM + ARP - 1) / ARP : BM / RPP;
     constexpr unsigned OOB = 0xFFFFFFFFu;
     static_assert(WGM * WGN == 4, "4 waves");
-    static_assert(BM % 8 == 0, "tile rows must be a multiple of 8");
+    static_assert(BM % RPP == 0 || AV4, "tile rows must be a multiple of the staging pass");
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ float Bs[2][BN * LDK];
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
 
     // gather lanes: voxel column pcol, two rows per wave (row parity = half of the wave)
     const int pcol = tid & (BP - 1);
-    const int half = (tid >> 5) & 1;
-    // dY lanes (AV4): 4 consecutive voxels, 32 rows per pass
-    const int aq = tid & 7, arow = tid >> 3;
+    const int half = (tid / BP) % RW;      // which of the wave's RW rows this lane stages
+    // dY lanes (AV4): 4 consecutive voxels, ARP rows per pass
+    const int aq = tid % AQ, arow = tid / AQ;
 
     const int chunk_begin = slice * prm.chunks_per_slice;
     int chunk_end = chunk_begin + prm.chunks_per_slice;
@@ -139,17 +143,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
             const bool ok = pv && (unsigned)(t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(h0 + b_kh[b]) < (unsigned)prm.gH &&
                             (unsigned)(w0 + b_kw[b]) < (unsigned)prm.gW;
             const unsigned voff = ok ? (unsigned)(xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
-            // rows of block b handled by this thread: ci0 + 2*wave + half + 8*jj, jj = 0,1
+            // rows of block b handled by this thread: ci0 + RW*wave + half + RPP*jj
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int ci_u = b_ci0[b] + 2 * wave + 8 * jj;          // wave-uniform part
+            for (int jj = 0; jj < PB; ++jj) {
+                const int ci_u = b_ci0[b] + RW * wave + RPP * jj;       // wave-uniform part
                 unsigned v = voff;
                 int soff = ci_u * ch_bytes;
                 if (has_tail) {
                     if (ci_u + half >= prm.Cin) v = OOB;
                     if (ci_u >= prm.Cin) soff = 0;
                 }
-                breg[2 * b + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)v, soff, 0));
+                breg[PB * b + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)v, soff, 0));
             }
         }
         // ---- dY operand ----------------------------------------------------------------------
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
             const float* base = DY + (size_t)n4 * prm.M * prm.oS + (p4 - n4 * prm.oS);
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
-                int row = m0 + (arow + 32 * j) % BM;
+                int row = m0 + (arow + ARP * j) % BM;
                 row = row < prm.M ? row : prm.M - 1;
                 areg4[j] = *reinterpret_cast<const f32x4*>(base + (size_t)row * prm.oS);
             }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
             const unsigned dyb = pv ? 4u * (n * (unsigned)prm.M * (unsigned)prm.oS + r0) + (unsigned)(half * row_bytes) : OOB;
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
-                const int row_u = m0 + 2 * wave + 8 * j;              // wave-uniform part of the row
+                const int row_u = m0 + RW * wave + RPP * j;           // wave-uniform part of the row
                 unsigned v = (row_u + half < prm.M) ? dyb : OOB;
                 areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)v, row_u < prm.M ? row_u * row_bytes : 0, 0));
             }
@@ -181,18 +185,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams prm, const 
 #pragma unroll
         for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-                Bs[buf][(16 * b + 2 * wave + half + 8 * jj) * LDK + pcol] = breg[2 * b + jj];
+            for (int jj = 0; jj < PB; ++jj)
+                Bs[buf][(16 * b + RW * wave + half + RPP * jj) * LDK + pcol] = breg[PB * b + jj];
         if (AV4) {
 #pragma unroll
             for (int j = 0; j < APASS; ++j) {
-                float* dst = &As[buf][((arow + 32 * j) % BM) * LDK + 4 * aq];      // 8-B aligned (LDK even)
+                float* dst = &As[buf][((arow + ARP * j) % BM) * LDK + 4 * aq];     // 8-B aligned (LDK even)
                 *reinterpret_cast<float2*>(dst) = make_float2(areg4[j][0], areg4[j][1]);
                 *reinterpret_cast<float2*>(dst + 2) = make_float2(areg4[j][2], areg4[j][3]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < APASS; ++j) As[buf][(2 * wave + half + 8 * j) * LDK + pcol] = areg[j];
+            for (int j = 0; j < APASS; ++j) As[buf][(RW * wave + half + RPP * j) * LDK + pcol] = areg[j];
         }
     };
 
@@ -281,6 +285,11 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     }
 }
 
+static int wgrad_bp() {
+    if (const char* e = getenv("ZSV_WGRAD_BP")) return atoi(e) == 16 ? 16 : 32;
+    return 32;
+}
+
 struct WgradPlan {
     int cfg;        // 0: 144x128, 1: 128x128, 2: 64x128, 3: 80x128
     int bm, bn;
@@ -309,12 +318,13 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     pl.bn = 128;
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
-    const long chunks = (P + 31) / 32;
+    const int bp = wgrad_bp();
+    const long chunks = (P + bp - 1) / bp;
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     // one full round of resident workgroups (256 CUs x LDS-limited 2-3 per CU): every workgroup
     // then runs start to finish concurrently and the slab traffic is minimal
     const long resident = 256L * (pl.bm == 64 ? 3 : 2);
-    long max_slices = (chunks + 15) / 16;                // at least 16 chunks (512 voxels) per slice
+    long max_slices = (chunks * bp + 511) / 512;         // at least 512 voxels per slice
     if (max_slices < 1) max_slices = 1;
     if (max_slices > 1024) max_slices = 1024;
     // pick the slice count whose workgroup count fills whole rounds best (fewer slices on ties:
@@ -338,10 +348,14 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
 template <int TM, int TN, int WGM, int WGN>
 static void wgrad_launch(const WgradParams& p, bool av4, dim3 grid, hipStream_t stream, const float* x, const float* dy,
                          float* out, int tiles_m, int tiles_mn) {
-    if (av4)
-        hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+    const int bp = wgrad_bp();
+    if (bp == 16) {
+        if (av4) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true, 16>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false, 16>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+    } else {
+        if (av4) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true, 32>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false, 32>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+    }
 }
 
 }  // namespace zsv
