@@ -84,6 +84,20 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("ZSV_CPU_THREADS", "64"))))
 
 
+def pmc_traffic(n_clips: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_s1_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of
+    tools/conv_bench.py at N = 22).  Counters cannot be read inside this process; None when the
+    batch differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_s1_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]["conv_tap_dma_kernel<9, 2, 1, 4, 1>"]
+        return round(k["hbm_bytes"]) if n_clips == CLIPS_PER_GPU else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(network: str, steps: int):
     """Config A of BASELINE.md on the host cores: oracle train step, N = 2 clips."""
     from oracle import restatement as R
@@ -175,8 +189,9 @@ def main():
     if rank == 0:
         total_clips = world * args.batch * args.steps
         value = total_clips / elapsed
+        label = {"r2plus1d_18": "R(2+1)D-18"}.get(args.network, args.network)
         out = {
-            "metric": "clips/sec (fwd+bwd+step) R(2+1)D-18 16x112x112 bs=22/GPU",
+            "metric": f"clips/sec (fwd+bwd+step) {label} 16x112x112 bs={args.batch}/GPU",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -188,8 +203,9 @@ def main():
         }
         # whole-step fractions of the two rooflines SURVEY section 8d defines
         per_gpu = value / world
-        out["step_roofline"] = {"fp32_flop_frac": round(per_gpu * 242.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
-                                "hbm_frac_unfused_bytes": round(per_gpu * 5.03e9 / 8.0e12, 4)}
+        if args.network.startswith("r2plus1d"):
+            out["step_roofline"] = {"fp32_flop_frac": round(per_gpu * 242.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+                                    "hbm_frac_unfused_bytes": round(per_gpu * 5.03e9 / 8.0e12, 4)}
         if timer is not None and timer.pairs:
             ms = timer.durations_ms()
             mean_ms = sum(ms) / len(ms)
@@ -197,12 +213,12 @@ def main():
             flops = 2.0 * n * 144 * 64 * 9 * 16 * 56 * 56          # 8.324 GFLOP/clip
             alg_bytes = 4.0 * (n * 64 * 16 * 56 * 56 + n * 144 * 16 * 56 * 56 + 144 * 64 * 9)
             achieved = flops / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "conv_igemm_kernel<fwd> 64->144 1x3x3 @16x56x56 (4 launches/step)",
+            out["roofline"] = {"kernel": "zsv::conv_tap_dma_kernel<9, 2, 1, 4, 1, 4, 9> = Conv3d(64,144,(1,3,3)) forward @16x56x56, 4 launches/step",
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
                                "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
-                               "traffic": None}
+                               "traffic": pmc_traffic(n)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.network, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -259,7 +259,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define WAVES_PER_EU 4
 #endif
 
-template <int TM, int TN, int WGM, int WGN, int FK>     // FK = MFMA k-steps per fragment burst (1 or 2)
+// NBLK_CT / TAPS_CT: compile-time channel-block and tap counts (0 = run time).  The one
+// specialisation (4, 9) is the network's dominant layer, Conv3d(64, 144, (1,3,3)) forward: its
+// chunk walk is fully constant-folded, and it gets a kernel symbol of its own in profiles.
+template <int TM, int TN, int WGM, int WGN, int FK, int NBLK_CT = 0, int TAPS_CT = 0>     // FK = MFMA k-steps per fragment burst
 __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmParams prm, const float* __restrict__ Wp,
                                                            const float* __restrict__ G, const float* __restrict__ bias,
                                                            float* __restrict__ C, int tiles_m, int Mp, int nblk) {
@@ -343,11 +346,13 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     const size_t a_chunk_stride = (size_t)BK * Mp;
     const int ch_bytes = 4 * prm.gS;
 
-    const int nchunks_all = (prm.K > 0) ? prm.taps * nblk : 0;
+    const int taps_ = TAPS_CT ? TAPS_CT : prm.taps;
+    const int nblk_ = NBLK_CT ? NBLK_CT : nblk;
+    const int nchunks_all = (prm.K > 0) ? taps_ * nblk_ : 0;
     const int per_split = (nchunks_all + prm.ksplit - 1) / prm.ksplit;
     const int c_begin = split * per_split;
     const int nchunks = max(0, min(nchunks_all, c_begin + per_split) - c_begin);
-    int ld_cb = c_begin / prm.taps, ld_tap = c_begin - ld_cb * prm.taps;
+    int ld_cb = c_begin / taps_, ld_tap = c_begin - ld_cb * taps_;
     auto issue_chunk = [&](int chunk, int buf) {
         const int toff = sgpr(tapoff[ld_tap]);
         const unsigned ok = (vmask >> ld_tap) & 1u;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
                 __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)(c_begin + chunk) * a_chunk_stride,
                                                  (lds_ptr_t)(&As[buf][256 * (wave + 4 * j)]), 16, 0, 0);
         }
-        if (++ld_tap == prm.taps) { ld_tap = 0; ++ld_cb; }
+        if (++ld_tap == taps_) { ld_tap = 0; ++ld_cb; }
     };
 
     f32x4 acc[TM][TN];
@@ -502,9 +507,17 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     if (const char* e = getenv("ZSV_CONV_NB")) nb = atoi(e);
     if (const char* e = getenv("ZSV_CONV_DMA")) dma = atoi(e);
     if (prm.ksplit > 1 && dma == 0) dma = 1;         // split-K lives in the DMA kernel
-    if (dma == 1)
+    if (dma == 1) {
+        if constexpr (TM == 9 && TN == 2) {
+            if (prm.dir == 1 && prm.taps == 9 && nblk == 4 && prm.ksplit <= 1 && !getenv("ZSV_NO_SPECIAL")) {
+                hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1, 4, 9>), dim3((unsigned)blocks), dim3(256), 0,
+                                   stream, prm, Wp, G, bias, C, tiles_m, Mp, nblk);
+                return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+            }
+        }
         hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
                            Wp, G, bias, C, tiles_m, Mp, nblk);
+    }
     else if (dma == 2)
         hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
                            Wp, G, bias, C, tiles_m, Mp, nblk);
