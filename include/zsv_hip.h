@@ -92,12 +92,13 @@ int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, const float
                     const float* beta, const float* running_mean, const float* running_var,
                     const float* residual, int fuse_relu, float eps, float* y, void* workspace,
                     size_t workspace_bytes, void* stream);
-/* Backward of the fused op.  `y` is the saved OUTPUT (needed only when fuse_relu, as the
- * ReLU mask, cf. nn.ReLU(inplace=True) which also keeps only its output).  Writes
- * dx, dgamma, dbeta and, when d_residual != NULL, the gradient flowing into the
- * residual branch (= dy masked by the ReLU). */
+/* Backward of the fused op.  fuse_relu: 0 = none; 1 = ReLU mask from the saved OUTPUT `y`
+ * (cf. nn.ReLU(inplace=True), which also keeps only its output); 2 = ReLU mask recomputed from x
+ * with the forward's exact fma (x*scale + shift > 0) -- valid when the forward had no residual
+ * input, `y` may then be NULL and one tensor read is saved per pass.  Writes dx, dgamma, dbeta
+ * and, when d_residual != NULL, the gradient flowing into the residual branch (= masked dy). */
 int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
-               const float* gamma, const float* save_mean, const float* save_invstd,
+               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                int fuse_relu, float* dx, float* d_residual, float* dgamma, float* dbeta,
                void* workspace, size_t workspace_bytes, void* stream);
 

@@ -41,7 +41,7 @@ SIGNATURES = {
                                  c_float, c_float, _P, c_size_t, _P]),
     "zsv_bn_fwd_eval": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int, c_float, _P, _P,
                                 c_size_t, _P]),
-    "zsv_bn_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
+    "zsv_bn_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
                            c_size_t, _P]),
     "zsv_relu_fwd": (c_int, [_P, _P, c_int64, _P]),
     "zsv_relu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),

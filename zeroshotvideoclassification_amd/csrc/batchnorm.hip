@@ -126,7 +126,7 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C,
     const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
     const float sc = g * (float)invstd;
     scale[c] = sc;
-    shift[c] = bt - (float)mean * sc;
+    shift[c] = __fmaf_rn(-(float)mean, sc, bt);      // (the backward recomputes exactly this)
 }
 
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if ((S % 4) == 0) {
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             float4 v = *reinterpret_cast<const float4*>(x + base + s);
-            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh);
             if (RES) {
                 const float4 r = *reinterpret_cast<const float4*>(res + base + s);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         }
     } else {
         for (int s = s0 + threadIdx.x; s < s1; s += 256) {
-            float v = x[base + s] * sc + sh;
+            float v = __fmaf_rn(x[base + s], sc, sh);
             if (RES) v += res[base + s];
             if (RELU) v = fmaxf(v, 0.f);
             y[base + s] = v;
@@ -177,12 +177,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// ---- backward reduce: sum g, sum g*xhat with g = dy * (y > 0 if RELU) -----------------
-template <bool RELU>
+// ---- backward reduce: sum g, sum g*xhat with g = dy * mask ------------------------------
+// RELU: 0 no mask; 1 mask = (saved output y > 0); 2 mask = (x*scale + shift > 0), i.e. the
+// pre-activation recomputed with the forward's exact fma -- saves reading y when the forward
+// had no residual input.
+template <int RELU>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ y, int N, int C, int S,
                                                             int slices, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
                                                             double* __restrict__ part) {
     __shared__ double red[4];
     const int c = blockIdx.x, sl = blockIdx.y;
@@ -190,6 +195,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     int b, e;
     slice_range(N * S, slices, sl, vec, b, e);
     const float mu = mean[c], is = invstd[c];
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    const float sh = __fmaf_rn(-mu, sc, beta ? beta[c] : 0.f);
     float s1 = 0.f, s2 = 0.f;
     if (vec) {
         for (int i = b + 4 * (int)threadIdx.x; i < e; i += 4 * 256) {
@@ -197,10 +204,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             const size_t off = ((size_t)n * C + c) * S + s;
             float4 g = *reinterpret_cast<const float4*>(dy + off);
             const float4 xv = *reinterpret_cast<const float4*>(x + off);
-            if (RELU) {
+            if (RELU == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + off);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            } else if (RELU == 2) {
+                g.x = __fmaf_rn(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = __fmaf_rn(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+                g.z = __fmaf_rn(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = __fmaf_rn(xv.w, sc, sh) > 0.f ? g.w : 0.f;
             }
             s1 += (g.x + g.y) + (g.z + g.w);
             s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) +
@@ -211,7 +221,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             const int n = i / S, s = i - n * S;
             const size_t off = ((size_t)n * C + c) * S + s;
             float g = dy[off];
-            if (RELU) g = y[off] > 0.f ? g : 0.f;
+            if (RELU == 1) g = y[off] > 0.f ? g : 0.f;
+            else if (RELU == 2) g = __fmaf_rn(x[off], sc, sh) > 0.f ? g : 0.f;
             s1 += g;
             s2 += g * ((x[off] - mu) * is);
         }
@@ -230,7 +241,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
-                                       float* __restrict__ ck) {
+                                       float* __restrict__ ck, const float* __restrict__ beta,
+                                       float* __restrict__ csh) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double sg = 0.0, sgx = 0.0;
@@ -248,17 +260,24 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
     ca[c] = (float)a;
     cb[c] = (float)b;
     ck[c] = (float)k;
+    // forward's shift, recomputed with the forward's exact arithmetic (its scale is gamma*invstd in fp32)
+    const float sc = (gamma ? gamma[c] : 1.f) * invstd[c];
+    csh[c] = __fmaf_rn(-mean[c], sc, beta ? beta[c] : 0.f);
 }
 
-template <bool RELU, bool DRES>
+template <int RELU, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, float* __restrict__ dx,
                                                            float* __restrict__ dres, int C, int S,
                                                            const float* __restrict__ ca, const float* __restrict__ cb,
-                                                           const float* __restrict__ ck) {
+                                                           const float* __restrict__ ck, const float* __restrict__ gamma,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ csh) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float a = ca[c], b = cb[c], k = ck[c];
+    const float sc = RELU == 2 ? (gamma ? gamma[c] : 1.f) * invstd[c] : 0.f;
+    const float sh = RELU == 2 ? csh[c] : 0.f;
     const size_t base = (size_t)row * S;
     const int s0 = blockIdx.y * ROW_CHUNK;
     const int s1 = min(S, s0 + ROW_CHUNK);
@@ -266,10 +285,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             float4 g = *reinterpret_cast<const float4*>(dy + base + s);
             const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
-            if (RELU) {
+            if (RELU == 1) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + base + s);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            } else if (RELU == 2) {
+                g.x = __fmaf_rn(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = __fmaf_rn(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+                g.z = __fmaf_rn(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = __fmaf_rn(xv.w, sc, sh) > 0.f ? g.w : 0.f;
             }
             if (DRES) *reinterpret_cast<float4*>(dres + base + s) = g;
             float4 o;
@@ -280,9 +302,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     } else {
         for (int s = s0 + threadIdx.x; s < s1; s += 256) {
             float g = dy[base + s];
-            if (RELU) g = y[base + s] > 0.f ? g : 0.f;
+            const float xs = x[base + s];
+            if (RELU == 1) g = y[base + s] > 0.f ? g : 0.f;
+            else if (RELU == 2) g = __fmaf_rn(xs, sc, sh) > 0.f ? g : 0.f;
             if (DRES) dres[base + s] = g;
-            dx[base + s] = a * g + b * x[base + s] + k;
+            dx[base + s] = a * g + b * xs + k;
         }
     }
 }
@@ -349,35 +373,34 @@ extern "C" int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, 
 }
 
 extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32_t N, int32_t C, int32_t S,
-                          const float* gamma, const float* save_mean, const float* save_invstd, int fuse_relu,
-                          float* dx, float* d_residual, float* dgamma, float* dbeta, void* workspace,
+                          const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                          int fuse_relu, float* dx, float* d_residual, float* dgamma, float* dbeta, void* workspace,
                           size_t workspace_bytes, void* stream_) {
     int st = check_ncs(N, C, S);
     if (st) return st;
     if (!dy || !x || !dx || !save_mean || !save_invstd || !workspace) return ZSV_E_NULL;
-    if (fuse_relu && !y) return ZSV_E_NULL;
+    if (fuse_relu < 0 || fuse_relu > 2) return ZSV_E_BAD_SHAPE;
+    if (fuse_relu == 1 && !y) return ZSV_E_NULL;
     if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int slices = bn_slices(N, C, S);
     BnWs w = bn_ws(workspace, C, slices);
-    if (fuse_relu)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), dim3(C, slices), dim3(256), 0, stream, dy, x, y, N, C, S, slices,
-                           save_mean, save_invstd, w.part);
+    const dim3 rgrid(C, slices);
+    if (fuse_relu == 2)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
+    else if (fuse_relu == 1)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), dim3(C, slices), dim3(256), 0, stream, dy, x, y, N, C, S, slices,
-                           save_mean, save_invstd, w.part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
     if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C, slices,
-                       (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1);
+                       (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
     if ((st = launch_status())) return st;
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
-    if (fuse_relu && d_residual)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
-    else if (fuse_relu)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
-    else if (d_residual)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1);
+#define ZSV_BWD_APPLY(R, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, D>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1, gamma, save_invstd, w.c2)
+    if (fuse_relu == 2) { if (d_residual) ZSV_BWD_APPLY(2, true); else ZSV_BWD_APPLY(2, false); }
+    else if (fuse_relu == 1) { if (d_residual) ZSV_BWD_APPLY(1, true); else ZSV_BWD_APPLY(1, false); }
+    else { if (d_residual) ZSV_BWD_APPLY(0, true); else ZSV_BWD_APPLY(0, false); }
+#undef ZSV_BWD_APPLY
     return launch_status();
 }

@@ -222,7 +222,8 @@ class _BatchNormAct(Function):
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         ctx.dims = (n, c, s)
-        ctx.save_for_backward(x, gamma, save_mean, save_invstd, y if relu else None)
+        # with a ReLU but no residual the backward recomputes the mask from x: y need not be kept
+        ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd, y if (relu and residual is not None) else None)
         return y
 
     @staticmethod
@@ -231,7 +232,7 @@ class _BatchNormAct(Function):
         if not ctx.training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the hot path "
                                "(the reference evaluates under torch.no_grad(), main.py:230)")
-        x, gamma, save_mean, save_invstd, y = ctx.saved_tensors
+        x, gamma, beta, save_mean, save_invstd, y = ctx.saved_tensors
         n, c, s = ctx.dims
         lib = _lib.load()
         dy = dy.contiguous()
@@ -244,8 +245,9 @@ class _BatchNormAct(Function):
         nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
         ws = _workspace(nbytes, x.device)
         with torch.cuda.device(x.device):
-            _lib.check(lib.zsv_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), n, c, s, _ptr(gamma), save_mean.data_ptr(),
-                                      save_invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), _ptr(dres),
+            mode = 0 if not ctx.relu else (1 if ctx.has_res else 2)
+            _lib.check(lib.zsv_bn_bwd(dy.data_ptr(), x.data_ptr(), _ptr(y), n, c, s, _ptr(gamma), _ptr(beta),
+                                      save_mean.data_ptr(), save_invstd.data_ptr(), mode, dx.data_ptr(), _ptr(dres),
                                       dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
         if want_res and not ctx.relu:
             dres = dy
