@@ -173,3 +173,47 @@ def test_evaluate_protocol_on_gpu():
     res = train.evaluate(model, batches, classes)
     assert res["n"] == 5
     assert 0.0 <= res["accuracy"] <= res["accuracy_top5"] <= 100.0
+
+
+def test_gradient_sync_on_rccl_single_rank():
+    """The RCCL code path of ddp.GradientSync (side stream, events, bucket pack/unpack) on the one
+    GPU this box has: world_size 1, so averaged gradients must equal the local ones."""
+    import os
+    import torch.distributed as dist
+    from zeroshotvideoclassification_amd import ddp
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29531"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        g, model, _ = build("r2plus1d_small")
+        x, z = case_inputs(g)
+        xd, zd = x.to(DEV), z.to(DEV)
+        model.train()
+        crit = torch.nn.MSELoss()
+        # reference gradients without the sync
+        y = train.embed(model, xd)
+        crit(y, zd).backward()
+        ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        rs = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+        model.zero_grad(set_to_none=True)
+        model.load_state_dict({**model.state_dict(), **rs})
+
+        sync = ddp.GradientSync(model, bucket_bytes=8 * 1024 * 1024)
+        opt = torch.optim.Adam(model.parameters(), lr=0.0)              # lr 0: parameters stay put
+        for step in range(2):                                            # discovery step, then overlapped step
+            train.train_step(model, opt, crit, xd, zd, sync)
+            torch.cuda.synchronize()
+            got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+            assert got.keys() == ref.keys()
+            for k in ref:
+                assert torch.allclose(got[k], ref[k], rtol=1e-5, atol=1e-9), (step, k)
+        assert sync.live_parameter_count == len(ref) == len(g["live_params"])   # dead tensors (SURVEY F5) excluded
+        assert sum(sync.bucket_sizes) == 31716681
+        assert len(sync.bucket_sizes) >= 4
+        first = sync._buckets[0].params[0]
+        assert any(first is p for p in model.output2emb_proj.parameters())   # head first, stem last
+        sync.remove()
+    finally:
+        dist.destroy_process_group()
