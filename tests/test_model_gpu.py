@@ -217,3 +217,47 @@ def test_gradient_sync_on_rccl_single_rank():
         sync.remove()
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_batch22_forward_matches_oracle_and_is_deterministic():
+    """BASELINE configs[1] geometry (22 clips of 3x16x112x112, train-mode BN): forward + loss against
+    the CPU oracle run here on the same weights and clips, run-to-run bitwise determinism of forward
+    and gradients, and the size-independent property that eval-mode embeddings of a clip do not
+    depend on its batch mates."""
+    from oracle import restatement as R
+    opt = make_opt("r2plus1d_18")
+    model = network.get_network(opt)
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=True)
+    model.load_state_dict(weights)
+    oracle = R.oracle_network(opt)
+    oracle.load_state_dict(weights)
+    x = synthetic.synthetic_clips(22, 16, 112)
+    _, z = synthetic.synthetic_targets(22)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle.train()
+    with torch.no_grad():
+        y_ref = R.embed(oracle, x)
+        loss_ref = F.mse_loss(y_ref, z)
+
+    model.to(DEV).train()
+    xd, zd = x.to(DEV), z.to(DEV)
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(weights)                     # reset running statistics
+        model.zero_grad(set_to_none=True)
+        y = train.embed(model, xd)
+        loss = F.mse_loss(y, zd)
+        loss.backward()
+        runs.append((y.detach().clone(), loss.detach().clone(),
+                     model.model.stem[0].weight.grad.clone(), model.model.layer1[0].conv1[0][0].weight.grad.clone()))
+    assert rel_err(runs[0][0].cpu().numpy(), y_ref.numpy()) < TIGHT
+    assert abs(runs[0][1].item() / loss_ref.item() - 1) < TIGHT
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b), "two identical steps must agree bit for bit"
+
+    model.eval()
+    with torch.no_grad():
+        full = train.embed(model, xd)
+        for i in (0, 7, 21):
+            single = train.embed(model, xd[i:i + 1])
+            assert rel_err(single.cpu().numpy(), full[i:i + 1].cpu().numpy()) < 1e-5
