@@ -30,6 +30,7 @@ struct IgemmParams {
     int relu;
     int ksplit;     // > 1: the K range is cut into ksplit parts, each writing a partial C slab
     int slab_elems; // elements of one C slab (= N * M * oS)
+    int lds_epilogue;   // 1: output rows are voxel-contiguous -> LDS-transposed full-line stores
     int debug;      // timing experiments only (ZSV_CONV_DEBUG): 1 skip global loads, 2 skip LDS stores, 4 skip barrier
 };
 
@@ -67,6 +68,60 @@ __device__ __forceinline__ void store_tiles(const IgemmParams& prm, const f32x4 
                     if (prm.relu) v = fmaxf(v, 0.f);
                     cbase[(size_t)m * prm.oS] = v;
                 }
+            }
+        }
+    }
+}
+
+// ---- LDS-transposed epilogue: full-line stores ------------------------------------------------
+// The accumulator layout puts 16 consecutive voxels of one channel on 16 lanes (64-B store
+// segments).  When the produced tensor is voxel-contiguous for this launch (stW == 1, oS % 4 == 0)
+// the workgroup instead transposes RP-row slices of its BM x BN tile through LDS (`cs`, aliasing the
+// staging buffers, row pitch BN + 4 floats) and every wave-instruction stores whole 512-B (BN = 128)
+// or 1-KB (BN = 256) channel rows with 16-B lanes.  `cap` = floats available in `cs`.
+// All 256 threads must call it (it contains barriers).
+template <int TM, int TN, int WGM, int WGN>
+__device__ __forceinline__ void store_tiles_lds(const IgemmParams& prm, const f32x4 (&acc)[TM][TN], float* cs, int cap,
+                                                int m0, int n0, int wave, int lane, const float* __restrict__ bias,
+                                                float* __restrict__ C) {
+    constexpr int BM = 16 * TM * WGM;
+    constexpr int BN = 16 * TN * WGN;
+    constexpr int PITCH = BN + 4;
+    constexpr int RPI = 256 / BN == 0 ? 1 : 256 / BN;      // rows per wave-instruction of the read-back (2 or 1)
+    static_assert(BN == 128 || BN == 256, "read-back assumes 32 or 64 float4 per row");
+    const int wm0 = (wave / WGN) * (16 * TM);
+    const int wn0 = (wave % WGN) * (16 * TN);
+    const int frag_row = lane >> 4, frag_col = lane & 15;
+    int rp = (cap / PITCH) & ~15;                         // rows per pass: multiple of 16 that fits
+    if (rp > BM) rp = BM;
+    const int c4 = BN == 128 ? (lane & 31) : lane;          // float4 column handled in the read-back
+    const int rsub = BN == 128 ? (lane >> 5) : 0;
+    for (int r0 = 0; r0 < BM; r0 += rp) {
+        __syncthreads();                                    // previous pass read back / main loop done
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rb = wm0 + 16 * i - r0;               // first row of tile i inside this pass
+            if (rb >= 0 && rb < rp) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        cs[(rb + 4 * frag_row + r) * PITCH + wn0 + 16 * j + frag_col] = acc[i][j][r];
+            }
+        }
+        __syncthreads();
+        const int rows = min(rp, BM - r0);
+        const int p = n0 + 4 * c4;                          // 4 voxels of one clip (oS % 4 == 0)
+        const bool pvalid = p < prm.P;
+        const int n = pvalid ? p / prm.cS : 0;
+        float* cbase = C + (size_t)n * prm.M * prm.oS + (p - n * prm.cS);
+        for (int rr = wave * RPI + rsub; rr < rows; rr += 4 * RPI) {
+            const int m = m0 + r0 + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&cs[rr * PITCH + 4 * c4]);
+            if (pvalid && m < prm.M) {
+                if (bias != nullptr) { const float b = bias[m]; v[0] += b; v[1] += b; v[2] += b; v[3] += b; }
+                if (prm.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<f32x4*>(cbase + (size_t)m * prm.oS) = v;
             }
         }
     }

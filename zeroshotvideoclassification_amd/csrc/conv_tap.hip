@@ -281,9 +281,11 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     constexpr int APASS = (ASLOTS + 255) / 256;
     constexpr unsigned OOB = 0xFFFFFFFFu;
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    // one LDS pool: As[2] | Bs[2] during the main loop, re-used by the transposing epilogue
+    __shared__ __attribute__((aligned(16))) float pool[2 * BK * (LDA + LDB)];
     __shared__ int tapoff[32];
+    float (*As)[BK * LDA] = reinterpret_cast<float (*)[BK * LDA]>(pool);
+    float (*Bs)[BK * LDB] = reinterpret_cast<float (*)[BK * LDB]>(pool + 2 * BK * LDA);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -427,13 +429,21 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
         __syncthreads();
     }
 
+    IgemmParams q = prm;
+    const float* ebias = bias;
+    float* Cout = C;
     if (prm.ksplit > 1) {                    // raw partial sums; bias / ReLU are applied by the slab reduce
-        IgemmParams q = prm;
         q.relu = 0;
-        store_tiles<TM, TN>(q, acc, m0 + wm0, n0 + wn0, lane, nullptr, C + (size_t)split * prm.slab_elems);
-    } else {
-        store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
+        ebias = nullptr;
+        Cout = C + (size_t)split * prm.slab_elems;
     }
+    if constexpr (BN == 128 || BN == 256) {
+        if (prm.lds_epilogue) {              // voxel-contiguous output: full-line stores through LDS
+            store_tiles_lds<TM, TN, WGM, WGN>(q, acc, pool, 2 * BK * (LDA + LDB), m0, n0, wave, lane, ebias, Cout);
+            return;
+        }
+    }
+    store_tiles<TM, TN>(q, acc, m0 + wm0, n0 + wn0, lane, ebias, Cout);
 #endif
 }
 
@@ -536,8 +546,11 @@ int igemm_tap_ksplit(const IgemmParams& prm) {
     tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
     const long tiles = (long)tiles_m * (((long)prm.P + kTapCfgs[cfg].bn - 1) / kTapCfgs[cfg].bn);
     const long nchunks = (long)prm.taps * nblk;
-    if (tiles >= 384 || nchunks < 32) return 1;
-    long ks = (768 + tiles - 1) / tiles;                 // aim at ~3 workgroups per CU
+    // 1024 workgroups are resident at once (256 CUs x 4); split K when one round is under-filled
+    long thresh = 700, target = 1024;
+    if (const char* e = getenv("ZSV_SPLITK_THRESH")) thresh = atol(e);
+    if (tiles >= thresh || nchunks < 32) return 1;
+    long ks = (target + tiles / 2) / tiles;              // nearest whole multiple of the tile count
     if (ks > nchunks / 12) ks = nchunks / 12;            // >= 12 chunks per part
     if (ks > 16) ks = 16;
     return ks < 2 ? 1 : (int)ks;
@@ -550,6 +563,10 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     IgemmParams prm = prm_in;
     if (const char* e = getenv("ZSV_CONV_DEBUG")) prm.debug = atoi(e);
     if (prm.ksplit < 1 || !slabs) prm.ksplit = 1;
+    // the transposing epilogue needs 4 consecutive voxels of a launch column group to be 4
+    // consecutive, 16-B aligned floats of one clip
+    prm.lds_epilogue = (prm.stW == 1 && prm.stH == 1 && prm.stT == 1 && prm.oS % 4 == 0 && prm.cS == prm.oS &&
+                        (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !getenv("ZSV_NO_LDS_EPILOGUE")) ? 1 : 0;
     if (prm.ksplit > 1) C = slabs;                       // partial slabs instead of the output tensor
     const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
