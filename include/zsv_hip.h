@@ -55,6 +55,14 @@ const char* zsv_version(void);
  * `workspace` holds the weights re-packed tap-major for the fast kernel (query the size;
  * 0 means the call needs none).  It must be 16-byte aligned. */
 size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d);
+/* Same, and the epilogue also emits BatchNorm partial statistics of y: bn_partials[0..Cout*tiles)
+ * = per (channel, column tile) sums, then Cout*tiles sums of squares, tiles =
+ * zsv_conv3d_fwd_stat_tiles(d, y) (0 = this geometry cannot; then call the plain form).  Only
+ * without bias / ReLU.  Feeds zsv_bn_fwd_train_stats, which then skips its pass over y. */
+int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y);
+int zsv_conv3d_fwd_stats(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                         float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
                    float* y, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv3d_input_grad(dy, w): what autograd runs for every conv but the first.  Strided
@@ -87,6 +95,13 @@ int zsv_bn_fwd_train(const float* x, int32_t N, int32_t C, int32_t S, const floa
                      float* save_mean, float* save_invstd, float* running_mean,
                      float* running_var, float momentum, float eps, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* Same with the batch statistics taken from the producing convolution's epilogue partials
+ * (zsv_conv3d_fwd_stats) instead of a pass over x. */
+int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
+                           const float* beta, const float* residual, int fuse_relu, float* y,
+                           float* save_mean, float* save_invstd, float* running_mean,
+                           float* running_var, float momentum, float eps, const float* conv_partials,
+                           int32_t stat_tiles, void* workspace, size_t workspace_bytes, void* stream);
 /* Eval-mode forward (model.eval(), main.py:229): uses the running statistics. */
 int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
                     const float* beta, const float* running_mean, const float* running_var,

@@ -291,3 +291,30 @@ def test_conv3d_split_k_small_grid():
         close(yg, yr, what="split-K fwd")
         close(xg.grad, xr.grad, what="split-K dgrad")
         close(wg.grad, wr.grad, what="split-K wgrad")
+
+
+def test_conv_epilogue_statistics_feed_batchnorm():
+    # geometry on the fused path (voxel-contiguous output, S % 4 == 0): the BatchNorm that consumes
+    # the convolution's epilogue partials must agree with the one that makes its own pass
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(3, 32, 4, 12, 12, generator=g).to(DEV)
+    wt = (torch.randn(48, 32, 1, 3, 3, generator=g) * 0.1).to(DEV)
+    gamma = (torch.rand(48, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(48, generator=g).to(DEV)
+    y, stats = ops.conv3d(x, wt, None, 1, (0, 1, 1), want_stats=True)
+    assert stats is not None and stats.shape[:2] == (2, 48)
+    rm1, rv1 = torch.zeros(48, device=DEV), torch.ones(48, device=DEV)
+    rm2, rv2 = torch.zeros(48, device=DEV), torch.ones(48, device=DEV)
+    a = ops.batch_norm_act(y, gamma, beta, rm1, rv1, None, True, 0.1, 1e-5, True, stats=stats)
+    b = ops.batch_norm_act(y, gamma, beta, rm2, rv2, None, True, 0.1, 1e-5, True)
+    close(a, b, rtol=2e-6, what="bn(conv stats) vs bn(own stats)")
+    close(rm1, rm2, rtol=1e-6, what="running mean")
+    close(rv1, rv2, rtol=1e-6, what="running var")
+    ref = F.relu(F.batch_norm(F.conv3d(x.double().cpu(), wt.double().cpu(), padding=(0, 1, 1)), None, None,
+                              gamma.double().cpu(), beta.double().cpu(), training=True))
+    close(a, ref, what="conv+bn+relu vs fp64")
+    # geometries that cannot provide statistics return None and the BatchNorm makes its own pass
+    _, none_stats = ops.conv3d(x, wt, None, (1, 2, 2), (0, 1, 1), want_stats=True)      # oS = 4*6*6 ok -> may fuse
+    y2, s2 = ops.conv3d(x[:, :, :, :7, :7].contiguous(), wt, None, 1, (0, 1, 1), want_stats=True)   # S = 4*49: % 4 == 0
+    y3, s3 = ops.conv3d(x[:, :, :1, :7, :7].contiguous(), wt, None, 1, (0, 1, 1), want_stats=True)  # S = 49: no
+    assert s3 is None

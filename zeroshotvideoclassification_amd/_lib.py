@@ -30,6 +30,8 @@ SIGNATURES = {
     "zsv_version": (c_char_p, []),
     "zsv_conv3d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "zsv_conv3d_fwd_stat_tiles": (c_int32, [POINTER(ConvDesc), _P]),
+    "zsv_conv3d_fwd_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_int32, _P, c_size_t, _P]),
     "zsv_conv3d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
@@ -39,6 +41,8 @@ SIGNATURES = {
     "zsv_bn_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "zsv_bn_fwd_train": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
                                  c_float, c_float, _P, c_size_t, _P]),
+    "zsv_bn_fwd_train_stats": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P,
+                                       c_float, c_float, _P, c_int32, _P, c_size_t, _P]),
     "zsv_bn_fwd_eval": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int, c_float, _P, _P,
                                 c_size_t, _P]),
     "zsv_bn_bwd": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P,

@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// conv-epilogue partials [C][tiles] (sum) and [C][tiles] (sum of squares) -> part[2][C][1] in fp64
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                                 int C, int tiles, double* __restrict__ part) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+        s1 += (double)psum[(size_t)c * tiles + t];
+        s2 += (double)psq[(size_t)c * tiles + t];
+    }
+    const double t1 = block_sum_256<double>(s1, red);
+    const double t2 = block_sum_256<double>(s2, red);
+    if (threadIdx.x == 0) { part[c] = t1; part[C + c] = t2; }
+}
+
 __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C, int slices, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
@@ -340,14 +355,30 @@ extern "C" int zsv_bn_fwd_train(const float* x, int32_t N, int32_t C, int32_t S,
                                 const float* beta, const float* residual, int fuse_relu, float* y,
                                 float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                                 float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream_) {
+    return zsv_bn_fwd_train_stats(x, N, C, S, gamma, beta, residual, fuse_relu, y, save_mean, save_invstd, running_mean,
+                                  running_var, momentum, eps, nullptr, 0, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
+                                      const float* beta, const float* residual, int fuse_relu, float* y,
+                                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                      float momentum, float eps, const float* conv_partials, int32_t stat_tiles,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
     int st = check_ncs(N, C, S);
     if (st) return st;
     if (!x || !y || !save_mean || !save_invstd || !workspace) return ZSV_E_NULL;
     if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
-    const int slices = bn_slices(N, C, S);
+    int slices = bn_slices(N, C, S);
     BnWs w = bn_ws(workspace, C, slices);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+    if (conv_partials && stat_tiles > 0) {
+        // statistics were accumulated by the producing convolution's epilogue: no pass over x
+        hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
+                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, w.part);
+        slices = 1;
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+    }
     if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
                        slices, (double)N * S, gamma, beta, save_mean, save_invstd, running_mean, running_var,

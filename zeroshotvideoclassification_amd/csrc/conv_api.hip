@@ -94,13 +94,34 @@ extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
     return align256(igemm_tap_workspace_bytes(p)) + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
 }
 
+extern "C" int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    IgemmParams p;
+    fwd_params(p, d, 0);
+    return igemm_tap_stat_tiles(p, y);
+}
+
 extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
                               float* y, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream) {
+    return zsv_conv3d_fwd_stats(d, x, w, bias, y, fuse_relu, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_fwd_stats(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                                    float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     int st = conv_check(d);
     if (st) return st;
     if (!x || !w || !y) return ZSV_E_NULL;
     IgemmParams p;
     fwd_params(p, d, fuse_relu);
+    if (bn_partials) {
+        // the partials describe the raw convolution output: only without bias / ReLU, and only on the
+        // kernel path zsv_conv3d_fwd_stat_tiles() promised
+        if (bias || fuse_relu || stat_tiles <= 0 || stat_tiles != igemm_tap_stat_tiles(p, y)) return ZSV_E_UNSUPPORTED;
+        p.stat_sum = bn_partials;
+        p.stat_sq = bn_partials + (size_t)d->Cout * stat_tiles;
+        p.tiles_n = stat_tiles;
+    }
     if (igemm_tap_applicable(p)) {
         if (workspace_bytes < zsv_conv3d_fwd_workspace_bytes(d) || !workspace) return ZSV_E_WORKSPACE;
         const int ks = igemm_tap_ksplit(p);

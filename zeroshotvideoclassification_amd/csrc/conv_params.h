@@ -31,6 +31,9 @@ struct IgemmParams {
     int ksplit;     // > 1: the K range is cut into ksplit parts, each writing a partial C slab
     int slab_elems; // elements of one C slab (= N * M * oS)
     int lds_epilogue;   // 1: output rows are voxel-contiguous -> LDS-transposed full-line stores
+    float* stat_sum;    // != nullptr (lds_epilogue only): per (channel, column tile) partial sum and sum of
+    float* stat_sq;     //   squares of the produced values, [M][tiles_n] each -- BatchNorm statistics for free
+    int tiles_n;
     int debug;      // timing experiments only (ZSV_CONV_DEBUG): 1 skip global loads, 2 skip LDS stores, 4 skip barrier
 };
 
@@ -118,6 +121,21 @@ __device__ __forceinline__ void store_tiles_lds(const IgemmParams& prm, const f3
         for (int rr = wave * RPI + rsub; rr < rows; rr += 4 * RPI) {
             const int m = m0 + r0 + rr;
             f32x4 v = *reinterpret_cast<const f32x4*>(&cs[rr * PITCH + 4 * c4]);
+            if (prm.stat_sum != nullptr) {
+                // columns beyond P hold exact zeros (their gathered operand was zero): no masking
+                float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                for (int o = (BN == 128 ? 16 : 32); o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (c4 == 0 && m < prm.M) {
+                    const int tn = n0 / BN;
+                    prm.stat_sum[(size_t)m * prm.tiles_n + tn] = s1;
+                    prm.stat_sq[(size_t)m * prm.tiles_n + tn] = s2;
+                }
+            }
             if (pvalid && m < prm.M) {
                 if (bias != nullptr) { const float b = bias[m]; v[0] += b; v[1] += b; v[2] += b; v[3] += b; }
                 if (prm.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -142,6 +160,7 @@ size_t igemm_tap_workspace_bytes(const IgemmParams& prm);
 int igemm_tap(const IgemmParams& prm, const float* W, int w_m_stride, int w_c_stride, const float* G,
               const float* bias, float* C, void* workspace, size_t workspace_bytes, float* slabs, hipStream_t stream);
 int igemm_tap_ksplit(const IgemmParams& prm);     // suggested split of the K range (1 = none)
+int igemm_tap_stat_tiles(const IgemmParams& prm, const float* C);   // column tiles if the epilogue can emit BN partials, else 0
 int splitk_reduce(const float* slabs, int ksplit, long elems, int M, int oS, const float* bias, int relu, float* C,
                   hipStream_t stream);
 int conv_check(const zsv_conv_desc* d);

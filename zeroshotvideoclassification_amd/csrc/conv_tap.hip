@@ -540,6 +540,20 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
+static bool tap_lds_epilogue_ok(const IgemmParams& prm, const float* C) {
+    return prm.stW == 1 && prm.stH == 1 && prm.stT == 1 && prm.oS % 4 == 0 && prm.cS == prm.oS &&
+           (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !getenv("ZSV_NO_LDS_EPILOGUE");
+}
+
+int igemm_tap_stat_tiles(const IgemmParams& prm, const float* C) {
+    if (!igemm_tap_applicable(prm) || !tap_lds_epilogue_ok(prm, C) || getenv("ZSV_NO_FUSED_STATS")) return 0;
+    if (igemm_tap_ksplit(prm) > 1) return 0;
+    int cfg, tiles_m, Mp, nblk, Cpad;
+    tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
+    if (kTapCfgs[cfg].bn != 128 && kTapCfgs[cfg].bn != 256) return 0;
+    return (int)(((long)prm.P + kTapCfgs[cfg].bn - 1) / kTapCfgs[cfg].bn);
+}
+
 int igemm_tap_ksplit(const IgemmParams& prm) {
     if (getenv("ZSV_NO_SPLITK")) return 1;
     int cfg, tiles_m, Mp, nblk, Cpad;
@@ -565,8 +579,8 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     if (prm.ksplit < 1 || !slabs) prm.ksplit = 1;
     // the transposing epilogue needs 4 consecutive voxels of a launch column group to be 4
     // consecutive, 16-B aligned floats of one clip
-    prm.lds_epilogue = (prm.stW == 1 && prm.stH == 1 && prm.stT == 1 && prm.oS % 4 == 0 && prm.cS == prm.oS &&
-                        (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !getenv("ZSV_NO_LDS_EPILOGUE")) ? 1 : 0;
+    prm.lds_epilogue = tap_lds_epilogue_ok(prm, C) ? 1 : 0;
+    if (!prm.lds_epilogue || prm.ksplit > 1) { prm.stat_sum = nullptr; prm.stat_sq = nullptr; }
     if (prm.ksplit > 1) C = slabs;                       // partial slabs instead of the output tensor
     const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;

@@ -22,15 +22,17 @@ class Conv3d(nn.Conv3d):
                 or isinstance(self.padding, str):
             raise NotImplementedError("only dilation=1, groups=1, zero padding are on the hot path")
 
-    def forward(self, x, relu: bool = False):
-        return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding, relu=relu)
+    def forward(self, x, relu: bool = False, want_stats: bool = False):
+        """``want_stats=True`` returns ``(y, stats)``: BatchNorm partial statistics of ``y`` gathered in
+        the kernel epilogue (None when the geometry does not provide them)."""
+        return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding, relu=relu, want_stats=want_stats)
 
 
 class BatchNorm3d(nn.BatchNorm3d):
-    def forward(self, x, residual=None, relu: bool = False):
+    def forward(self, x, residual=None, relu: bool = False, stats=None):
         if x.dim() != 5:
             raise ValueError(f"expected 5D input (got {x.dim()}D input)")
-        return ops.bn_module_act(x, self, residual=residual, relu=relu)
+        return ops.bn_module_act(x, self, residual=residual, relu=relu, stats=stats)
 
 
 class ReLU(nn.ReLU):

@@ -109,7 +109,7 @@ class _Conv3d(Function):
     network.py:102-117), optional bias and fused ReLU (network.py:147-162)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats):
         _require(x, weight, bias)
         if x.dim() != 5 or weight.dim() != 5:
             raise RuntimeError("conv3d expects (N,C,T,H,W) input and (O,I,kT,kH,kW) weight")
@@ -122,20 +122,30 @@ class _Conv3d(Function):
         with torch.cuda.device(x.device):
             nbytes = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
             ws = _workspace(nbytes, x.device)
+            # BatchNorm partial statistics from the epilogue (consumed by the BatchNorm that follows)
+            tiles = 0
+            stats = None
+            if want_stats and bias is None and not relu:
+                tiles = lib.zsv_conv3d_fwd_stat_tiles(byref(d), y.data_ptr())
+                if tiles > 0:
+                    stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
             ev = timer.start() if (timer is not None and timer.wants("conv_fwd", d)) else None
-            _lib.check(lib.zsv_conv3d_fwd(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
-                                          1 if relu else 0, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd")
+            _lib.check(lib.zsv_conv3d_fwd_stats(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                1 if relu else 0, _ptr(stats), tiles, _ptr(ws), nbytes, _stream()),
+                       "zsv_conv3d_fwd")
             if ev is not None:
                 timer.stop(ev)
         ctx.desc = d
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
-        return y
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, weight, y = ctx.saved_tensors
         d = ctx.desc
         lib = _lib.load()
@@ -160,11 +170,14 @@ class _Conv3d(Function):
                                                 _stream()), "zsv_conv3d_wgrad")
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = channel_sum(dy)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False):
-    return _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu))
+def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False, want_stats=False):
+    """``want_stats``: also return the epilogue's BatchNorm partial statistics (or None when this
+    geometry does not produce them) as ``(y, stats)``."""
+    y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats))
+    return (y, stats) if want_stats else y
 
 
 def channel_sum(t: torch.Tensor) -> torch.Tensor:
@@ -189,8 +202,8 @@ class _BatchNormAct(Function):
     (resnet.py:110) + optional ReLU (resnet.py:49,95,111) in one pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu):
-        _require(x, gamma, beta, running_mean, running_var, residual)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, stats):
+        _require(x, gamma, beta, running_mean, running_var, residual, stats)
         x = x.contiguous()
         n, c = int(x.shape[0]), int(x.shape[1])
         s = x.numel() // (n * c)
@@ -207,11 +220,16 @@ class _BatchNormAct(Function):
             if training:
                 save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
                 save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-                _lib.check(lib.zsv_bn_fwd_train(x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), _ptr(residual),
-                                                1 if relu else 0, y.data_ptr(), save_mean.data_ptr(),
-                                                save_invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
-                                                float(momentum), float(eps), _ptr(ws), nbytes, _stream()),
-                           "zsv_bn_fwd_train")
+                tiles = 0
+                if stats is not None:
+                    if stats.dim() != 3 or stats.shape[0] != 2 or stats.shape[1] != c or not stats.is_contiguous():
+                        raise RuntimeError("conv statistics do not match this BatchNorm")
+                    tiles = int(stats.shape[2])
+                _lib.check(lib.zsv_bn_fwd_train_stats(x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), _ptr(residual),
+                                                      1 if relu else 0, y.data_ptr(), save_mean.data_ptr(),
+                                                      save_invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                      float(momentum), float(eps), _ptr(stats), tiles, _ptr(ws), nbytes,
+                                                      _stream()), "zsv_bn_fwd_train")
             else:
                 if running_mean is None or running_var is None:
                     raise RuntimeError("eval-mode BatchNorm needs running statistics")
@@ -253,16 +271,18 @@ class _BatchNormAct(Function):
             dres = dy
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if ctx.needs_input_grad[2] else None, None, None, dres if want_res else None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, training=True, momentum=0.1,
-                   eps=1e-5, relu=False):
+                   eps=1e-5, relu=False, stats=None):
+    """``stats``: BatchNorm partial statistics of ``x`` from the producing convolution's epilogue
+    (``conv3d(..., want_stats=True)``); the kernel then skips its own pass over ``x``."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
-                               float(eps), bool(relu))
+                               float(eps), bool(relu), stats if training else None)
 
 
-def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False):
+def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None):
     """Apply an ``nn.BatchNorm3d``-like module's parameters through the fused kernel, with
     torch's train/eval and running-statistics semantics (momentum=None -> cumulative average
     is not used anywhere in the reference and is rejected)."""
@@ -273,7 +293,7 @@ def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
     rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
-    return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu)
+    return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu, stats)
 
 
 # ------------------------------------------------------------------------------------------

@@ -28,27 +28,41 @@ from .layers import AdaptiveAvgPool3d, BatchNorm3d, Conv3d, Linear, ReLU
 __all__ = ["r3d_18", "mc3_18", "r2plus1d_18"]
 
 
-def _run_chain(mods: Sequence[nn.Module], x: Tensor) -> Tensor:
-    """Run conv / BN / ReLU children with BN+ReLU pairs fused into one kernel sequence."""
+def _call(m: nn.Module, x: Tensor, want_stats: bool):
+    """Run a conv-like child; with ``want_stats`` also fetch the BatchNorm partial statistics its
+    (last) convolution accumulated in the kernel epilogue."""
+    if want_stats and isinstance(m, (Conv3d, _FusedSequential)):
+        return m(x, want_stats=True)
+    return m(x), None
+
+
+def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
+    """Run conv / BN / ReLU children as fused kernel sequences: a convolution followed by a
+    training-mode BatchNorm hands over its epilogue statistics (no separate pass over the
+    activations), and BN + ReLU are one pass.  Returns ``(x, stats_of_last_conv_or_None)``."""
     mods = list(mods)
-    i = 0
-    while i < len(mods):
+    i, n = 0, len(mods)
+    stats = None
+    while i < n:
         m = mods[i]
-        if isinstance(m, BatchNorm3d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
-            x = m(x, relu=True)
-            i += 2
-        elif isinstance(m, _FusedSequential):
-            x = m(x)
-            i += 1
-        else:
-            x = m(x)
-            i += 1
-    return x
+        nxt = mods[i + 1] if i + 1 < n else None
+        if isinstance(m, BatchNorm3d):
+            relu = isinstance(nxt, nn.ReLU)
+            x = m(x, relu=relu, stats=stats)
+            stats = None
+            i += 2 if relu else 1
+            continue
+        feeds_bn = isinstance(nxt, BatchNorm3d) and nxt.training
+        last = i + 1 == n
+        x, stats = _call(m, x, feeds_bn or (last and want_stats))
+        i += 1
+    return x, stats
 
 
 class _FusedSequential(nn.Sequential):
-    def forward(self, x: Tensor) -> Tensor:
-        return _run_chain(list(self), x)
+    def forward(self, x: Tensor, want_stats: bool = False):
+        x, stats = _run_chain(list(self), x, want_stats)
+        return (x, stats) if want_stats else x
 
 
 class Conv3DSimple(Conv3d):
@@ -116,13 +130,14 @@ class BasicBlock(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         out = self.conv1(x)
-        out = self.conv2[0](out)
+        tail = self.conv2[1] if len(self.conv2) == 2 else None
+        fused_tail = isinstance(tail, BatchNorm3d)
+        out, stats = _call(self.conv2[0], out, fused_tail and tail.training)
         residual = x if self.downsample is None else self.downsample(x)
-        tail = self.conv2[1]
-        if len(self.conv2) == 2 and isinstance(tail, BatchNorm3d):
+        if fused_tail:
             # BN + `out += residual` + ReLU (resnet.py:97,110-111) in one pass
-            return tail(out, residual=residual, relu=True)
-        out = _run_chain(list(self.conv2)[1:], out)
+            return tail(out, residual=residual, relu=True, stats=stats)
+        out, _ = _run_chain(list(self.conv2)[1:], out)
         return ops.add_relu(out, residual)
 
 
@@ -146,9 +161,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         out = self.conv2(self.conv1(x))
-        out = self.conv3[0](out)
+        out, stats = _call(self.conv3[0], out, self.conv3[1].training)
         residual = x if self.downsample is None else self.downsample(x)
-        return self.conv3[1](out, residual=residual, relu=True)
+        return self.conv3[1](out, residual=residual, relu=True, stats=stats)
 
 
 class BasicStem(_FusedSequential):
