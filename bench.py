@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--network", default="r2plus1d_18")
     ap.add_argument("--batch", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--optimizer", choices=["fused", "torch"], default="torch",
+                    help="fused: zeroshotvideoclassification_amd.optim.FusedAdam (one launch, same update rule as "
+                         "torch.optim.Adam); torch: torch.optim.Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -138,7 +141,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
 
-    from zeroshotvideoclassification_amd import _lib, ddp, network, ops, synthetic, train
+    from zeroshotvideoclassification_amd import _lib, ddp, network, ops, optim, synthetic, train
     from types import SimpleNamespace
     _lib.load()
     torch.cuda.set_device(local_rank)
@@ -151,7 +154,10 @@ def main():
     model = network.get_network(SimpleNamespace(network=args.network, fixconvs=False, nopretrained=False))
     model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
     model.to(dev).train()
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if args.optimizer == "fused":
+        optimizer = optim.FusedAdam(model.parameters(), lr=1e-3)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
     criterion = torch.nn.MSELoss().to(dev)
     sync = ddp.GradientSync(model) if world > 1 else None
 
@@ -198,6 +204,7 @@ def main():
             "config": {"workload": f"{args.network} training step (zero_grad+fwd+MSE+bwd+Adam), {args.batch} clips/GPU "
                                    f"3x{FRAMES}x{SIZE}x{SIZE}, random-init, fp32 (BASELINE.json configs[1])",
                        "clips_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "optimizer": "Adam lr=1e-3 (" + ("fused multi-tensor HIP kernel" if args.optimizer == "fused" else "torch.optim.Adam") + ")",
                        "parallelism": f"dp{world}" + (" RCCL bucketed all-reduce overlapped with backward" if world > 1 else ""),
                        "final_loss": float(loss.item()) if loss is not None else None},
         }

@@ -161,6 +161,21 @@ int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
 int zsv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* The same update for every parameter tensor of a model in ONE launch (the reference's
+ * optimizer.step(), main.py:200, is ~113 tensors).  `table_device` is a device array of `count`
+ * descriptors sorted by first_chunk; a chunk is 4096 elements; first_chunk = running sum of
+ * ceil(n / 4096) over the preceding tensors; total_chunks = that sum over all tensors. */
+typedef struct zsv_adam_tensor {
+    float* p;
+    const float* g;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    int64_t first_chunk;
+} zsv_adam_tensor;
+int zsv_adam_multi(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

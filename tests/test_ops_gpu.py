@@ -318,3 +318,25 @@ def test_conv_epilogue_statistics_feed_batchnorm():
     y2, s2 = ops.conv3d(x[:, :, :, :7, :7].contiguous(), wt, None, 1, (0, 1, 1), want_stats=True)   # S = 4*49: % 4 == 0
     y3, s3 = ops.conv3d(x[:, :, :1, :7, :7].contiguous(), wt, None, 1, (0, 1, 1), want_stats=True)  # S = 49: no
     assert s3 is None
+
+
+def test_fused_multi_tensor_adam_matches_torch_adam():
+    from zeroshotvideoclassification_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(6)
+    shapes = [(5000,), (3, 7, 11), (1,), (4097,), (64, 64)]
+    ref_p = [torch.randn(*s, generator=g).requires_grad_() for s in shapes] + [torch.randn(9).requires_grad_()]
+    dev_p = [p.detach().clone().to(DEV).requires_grad_() for p in ref_p]
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-3)
+    dev_opt = FusedAdam(dev_p, lr=1e-3)
+    for step in range(3):
+        for rp, dp in zip(ref_p[:-1], dev_p[:-1]):             # the last parameter never gets a gradient
+            gr = torch.randn(rp.shape, generator=g)
+            rp.grad = gr.clone()
+            dp.grad = gr.to(DEV)
+        ref_opt.step()
+        dev_opt.step()
+    for rp, dp in zip(ref_p, dev_p):
+        close(dp, rp, rtol=1e-6, what="fused adam")
+    assert torch.equal(dev_p[-1].cpu(), ref_p[-1].detach())
+    sd = dev_opt.state_dict()["state"]
+    assert set(sd[0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd[0]["step"]) == 3.0

@@ -142,19 +142,21 @@ extern "C" int zsv_conv3d_fwd_stats(const zsv_conv_desc* d, const float* x, cons
 static int dgrad_plan(const zsv_conv_desc* d, size_t& wbytes) {
     IgemmParams p;
     int ks = 0;
-    bool all_tap = true;
+    bool all_tap = true, has_empty = false;
     wbytes = 0;
     for (int rt = 0; rt < d->sT; ++rt)
         for (int rh = 0; rh < d->sH; ++rh)
             for (int rw = 0; rw < d->sW; ++rw) {
                 if (!dgrad_class_params(p, d, rt, rh, rw)) continue;
+                if (p.K == 0) { has_empty = true; continue; }      // zero class: handled by a memset
                 if (!igemm_tap_applicable(p)) { all_tap = false; continue; }
                 const size_t b = align256(igemm_tap_workspace_bytes(p));
                 if (b > wbytes) wbytes = b;
                 const int k = igemm_tap_ksplit(p);
                 if (ks == 0 || k < ks) ks = k;
             }
-    return (all_tap && ks > 1) ? ks : 1;
+    // (split-K slabs would need the empty classes' voxels zeroed in every slab: keep it simple)
+    return (all_tap && !has_empty && ks > 1) ? ks : 1;
 }
 
 extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
@@ -177,11 +179,21 @@ extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const f
     if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
     float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
     IgemmParams p;
+    // residue classes that see no tap (e.g. 7 of the 8 classes of a 1x1x1 stride-2 shortcut) are
+    // exactly zero: clear dx once instead of launching a kernel per empty class
+    bool any_empty = false;
+    for (int rt = 0; rt < d->sT; ++rt)
+        for (int rh = 0; rh < d->sH; ++rh)
+            for (int rw = 0; rw < d->sW; ++rw)
+                if (dgrad_class_params(p, d, rt, rh, rw) && p.K == 0) any_empty = true;
+    if (any_empty && hipMemsetAsync(dx, 0, (size_t)out_elems * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return ZSV_E_LAUNCH;
     // one launch per residue class; the classes reuse the (stream-ordered) weight workspace
     for (int rt = 0; rt < d->sT; ++rt)
         for (int rh = 0; rh < d->sH; ++rh)
             for (int rw = 0; rw < d->sW; ++rw) {
                 if (!dgrad_class_params(p, d, rt, rh, rw)) continue;
+                if (p.K == 0) continue;                      // cleared above
                 if (igemm_tap_applicable(p)) {
                     p.ksplit = ks;
                     p.slab_elems = (int)out_elems;

@@ -306,6 +306,44 @@ extern "C" int zsv_adam_step(float* p, const float* g, float* exp_avg, float* ex
     return launch_status();
 }
 
+// ---- multi-tensor Adam: one launch for every parameter tensor of the model ---------------------
+// table[i] = {p, g, exp_avg, exp_avg_sq, n, first_chunk}; a chunk is 256 threads x 16 elements.
+namespace zsv {
+constexpr int ADAM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adam_multi_kernel(const zsv_adam_tensor* __restrict__ table, int count, float b1,
+                                                         float b2, float eps, float step_size, float inv_sqrt_bc2) {
+    // binary search: last tensor whose first_chunk <= blockIdx.x
+    int lo = 0, hi = count - 1;
+    const long chunk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const zsv_adam_tensor t = table[lo];
+    const long base = (chunk - t.first_chunk) * ADAM_CHUNK;
+    const long end = min(t.n, base + ADAM_CHUNK);
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+        const float gi = t.g[i];
+        const float mi = b1 * t.exp_avg[i] + (1.f - b1) * gi;
+        const float vi = b2 * t.exp_avg_sq[i] + (1.f - b2) * gi * gi;
+        t.exp_avg[i] = mi;
+        t.exp_avg_sq[i] = vi;
+        t.p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+}  // namespace zsv
+
+extern "C" int zsv_adam_multi(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks, float lr,
+                              float beta1, float beta2, float eps, int32_t step, void* stream) {
+    if (!table_device) return ZSV_E_NULL;
+    if (count <= 0 || total_chunks <= 0 || step <= 0 || total_chunks > 0x7fffffffL) return count == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(zsv::adam_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table_device,
+                       count, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+    return launch_status();
+}
+
 extern "C" const char* zsv_status_string(int status) {
     switch (status) {
         case ZSV_OK: return "ok";
