@@ -52,6 +52,7 @@ struct WgradParams {
     int sT, sH, sW, pT, pH, pW;
     int chunks_per_slice;   // 32-voxel chunks handled by one slice
     unsigned x_bytes, dy_bytes;
+    int debug;              // timing experiments (ZSV_WGRAD_DEBUG): 1 skip global loads, 2 skip LDS stores
 };
 
 template <int TM, int TN, int WGM, int WGN, bool AV4, int BP>      // BP = voxels per chunk (32 or 16)
@@ -126,59 +127,76 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
     const int ch_bytes = 4 * prm.gS;
     const int row_bytes = 4 * prm.oS;
 
-    auto load_chunk = [&](int chunk) {
-        // ---- gathered operand --------------------------------------------------------------
+    // The loads of chunk c+2 are issued in NG parts, one inside each MFMA group of chunk c, so their
+    // address arithmetic and issue slots hide under this wave's own MFMAs (an MFMA holds the issue
+    // port for 8 of its 32 cycles).  Part 0 decodes the chunk's voxels; the state lives in registers.
+    bool ld_pv = false;
+    int ld_t0 = 0, ld_h0 = 0, ld_w0 = 0, ld_xb = 0;
+    unsigned ld_dyb = OOB;
+    const float* ld_abase = DY;
+    auto load_decode = [&](int chunk) {
         const unsigned p = (unsigned)(chunk * BP + pcol);
-        const bool pv = p < (unsigned)prm.P;
+        ld_pv = p < (unsigned)prm.P;
         const unsigned n = mdiv(p, prm.m_oS);
         const unsigned r0 = p - n * prm.oS;
         const unsigned ot = mdiv(r0, prm.m_oHW);
         const unsigned r1 = r0 - ot * prm.oHW;
         const unsigned oh = mdiv(r1, prm.m_oW);
         const unsigned ow = r1 - oh * prm.oW;
-        const int t0 = (int)ot * prm.sT - prm.pT, h0 = (int)oh * prm.sH - prm.pH, w0 = (int)ow * prm.sW - prm.pW;
-        const int xb = 4 * ((int)n * prm.gCS + t0 * prm.gHW + h0 * prm.gW + w0) + half * ch_bytes;
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            const bool ok = pv && (unsigned)(t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(h0 + b_kh[b]) < (unsigned)prm.gH &&
-                            (unsigned)(w0 + b_kw[b]) < (unsigned)prm.gW;
-            const unsigned voff = ok ? (unsigned)(xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
-            // rows of block b handled by this thread: ci0 + RW*wave + half + RPP*jj
-#pragma unroll
-            for (int jj = 0; jj < PB; ++jj) {
-                const int ci_u = b_ci0[b] + RW * wave + RPP * jj;       // wave-uniform part
-                unsigned v = voff;
-                int soff = ci_u * ch_bytes;
-                if (has_tail) {
-                    if (ci_u + half >= prm.Cin) v = OOB;
-                    if (ci_u >= prm.Cin) soff = 0;
-                }
-                breg[PB * b + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)v, soff, 0));
-            }
-        }
-        // ---- dY operand ----------------------------------------------------------------------
+        ld_t0 = (int)ot * prm.sT - prm.pT; ld_h0 = (int)oh * prm.sH - prm.pH; ld_w0 = (int)ow * prm.sW - prm.pW;
+        ld_xb = 4 * ((int)n * prm.gCS + ld_t0 * prm.gHW + ld_h0 * prm.gW + ld_w0) + half * ch_bytes;
         if (AV4) {
             // 4 voxels of one clip (oS % 4 == 0); clamp instead of masking: rows >= M are never
             // stored, voxels >= P meet zeros from the gathered operand
             unsigned p4 = (unsigned)(chunk * BP + 4 * aq);
             if (p4 + 4 > (unsigned)prm.P) p4 = (unsigned)prm.P - 4;
             const unsigned n4 = mdiv(p4, prm.m_oS);
-            const float* base = DY + (size_t)n4 * prm.M * prm.oS + (p4 - n4 * prm.oS);
-#pragma unroll
-            for (int j = 0; j < APASS; ++j) {
-                int row = m0 + (arow + ARP * j) % BM;
-                row = row < prm.M ? row : prm.M - 1;
-                areg4[j] = *reinterpret_cast<const f32x4*>(base + (size_t)row * prm.oS);
-            }
+            ld_abase = DY + (size_t)n4 * prm.M * prm.oS + (p4 - n4 * prm.oS);
         } else {
-            const unsigned dyb = pv ? 4u * (n * (unsigned)prm.M * (unsigned)prm.oS + r0) + (unsigned)(half * row_bytes) : OOB;
-#pragma unroll
-            for (int j = 0; j < APASS; ++j) {
-                const int row_u = m0 + RW * wave + RPP * j;           // wave-uniform part of the row
-                unsigned v = (row_u + half < prm.M) ? dyb : OOB;
-                areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)v, row_u < prm.M ? row_u * row_bytes : 0, 0));
-            }
+            ld_dyb = ld_pv ? 4u * (n * (unsigned)prm.M * (unsigned)prm.oS + r0) + (unsigned)(half * row_bytes) : OOB;
         }
+    };
+    auto load_b = [&](int b) {          // gathered rows of 16-column block b
+        const bool ok = ld_pv && (unsigned)(ld_t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(ld_h0 + b_kh[b]) < (unsigned)prm.gH &&
+                        (unsigned)(ld_w0 + b_kw[b]) < (unsigned)prm.gW;
+        const unsigned voff = ok ? (unsigned)(ld_xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
+        // rows of block b handled by this thread: ci0 + RW*wave + half + RPP*jj
+#pragma unroll
+        for (int jj = 0; jj < PB; ++jj) {
+            const int ci_u = b_ci0[b] + RW * wave + RPP * jj;       // wave-uniform part
+            unsigned v = voff;
+            int soff = ci_u * ch_bytes;
+            if (has_tail) {
+                if (ci_u + half >= prm.Cin) v = OOB;
+                if (ci_u >= prm.Cin) soff = 0;
+            }
+            breg[PB * b + jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, (int)v, soff, 0));
+        }
+    };
+    auto load_a = [&](int j) {          // dY rows of staging pass j
+        if (AV4) {
+            int row = m0 + (arow + ARP * j) % BM;
+            row = row < prm.M ? row : prm.M - 1;
+            areg4[j] = *reinterpret_cast<const f32x4*>(ld_abase + (size_t)row * prm.oS);
+        } else {
+            const int row_u = m0 + RW * wave + RPP * j;           // wave-uniform part of the row
+            unsigned v = (row_u + half < prm.M) ? ld_dyb : OOB;
+            areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (int)v, row_u < prm.M ? row_u * row_bytes : 0, 0));
+        }
+    };
+    // part g of NGP: an even share of the blocks and of the dY passes
+    auto load_part = [&](int chunk, int g, int ngp) {
+        if (g == 0) load_decode(chunk);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b)
+            if (b * ngp / NBLK == g) load_b(b);
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            if (j * ngp / APASS == g) load_a(j);
+    };
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) load_part(chunk, g, 4);
     };
 
     auto store_chunk = [&](int buf) {
@@ -219,7 +237,9 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
     for (int ch = chunk_begin; ch < chunk_end; ++ch) {
         const int cur = (ch - chunk_begin) & 1;
         if (ch + 1 < chunk_end) store_chunk(cur ^ 1);
-        if (ch + 2 < chunk_end) load_chunk(ch + 2);
+        // always issue the loads (clamped chunk index in the last two iterations): a branch around
+        // them makes hipcc drain vmcnt(0) at every join and serialises the parts
+        const int lchunk = min(ch + 2, chunk_end - 1);
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
         float a[2][2][TM], b[2][2][TN];
@@ -237,6 +257,7 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) fetch(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);      // next group's ds_reads stay ahead of this group's MFMAs
+            load_part(lchunk, g, NG);               // same scheduling region as the MFMAs below
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -395,6 +416,8 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
+    p.debug = 0;
+    if (const char* e = getenv("ZSV_WGRAD_DEBUG")) p.debug = atoi(e);
 
     const bool av4 = (p.oS % 4 == 0) && (p.P >= 4) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
     const int tiles_mn = pl.tiles_m * pl.tiles_n;
