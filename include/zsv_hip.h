@@ -161,6 +161,17 @@ int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
 int zsv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* ---- clip pre-processing ------------------------------------------------------ */
+/* The reference's transform chain (auxiliary/transforms.py:41-56): (u8/255 - 1)/2 and THWC->CTHW
+ * (:116-117), bilinear resize of the short side to 128 with align_corners=False (:99-107), a
+ * crop x crop window at (top, left) of the resized frame (:80-97,132-158) and an optional horizontal
+ * flip (:188-195), fused into one pass.  frames_u8: (N, T, Hin, Win, 3) uint8;
+ * crop_flip_params_device: N x {top, left, flip} int32 on the device; out: (N, 3, T, crop, crop)
+ * fp32.  Hres/Wres = floor(Hin*scale), floor(Win*scale); inv_scale = (float)(1/scale). */
+int zsv_clip_transform(const uint8_t* frames_u8, int32_t N, int32_t T, int32_t Hin, int32_t Win,
+                       int32_t Hres, int32_t Wres, float inv_scale, int32_t crop,
+                       const int32_t* crop_flip_params_device, float* out, void* stream);
+
 /* The same update for every parameter tensor of a model in ONE launch (the reference's
  * optimizer.step(), main.py:200, is ~113 tensors).  `table_device` is a device array of `count`
  * descriptors sorted by first_chunk; a chunk is 4096 elements; first_chunk = running sum of
