@@ -34,7 +34,6 @@ struct IgemmParams {
     float* stat_sum;    // != nullptr (lds_epilogue only): per (channel, column tile) partial sum and sum of
     float* stat_sq;     //   squares of the produced values, [M][tiles_n] each -- BatchNorm statistics for free
     int tiles_n;
-    int debug;      // timing experiments only (ZSV_CONV_DEBUG): 1 skip global loads, 2 skip LDS stores, 4 skip barrier
 };
 
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };

@@ -1,25 +1,32 @@
-// conv_tap.hip -- tap-major implicit-GEMM convolution (forward and dgrad) for gfx950.
+// conv_tap.hip -- implicit-GEMM convolution (forward and dgrad) for gfx950, the hot kernel.
 //
-// Same GEMM view, tile shapes, MFMA (v_mfma_f32_16x16x4_f32, bit-exact fp32) and LDS images
-// as conv_igemm.hip, but the reduction index is ordered (tap, channel) instead of
-// (channel, tap), and a K-chunk is "one tap x 16 consecutive channels".  That removes the
-// per-element address arithmetic from the hot loop:
+// Same GEMM view as conv_igemm.hip -- C[m][p] = sum_k A[m][k] * B[k][p], rows = channels
+// produced, columns = voxels (n, t, h, w), MFMA v_mfma_f32_16x16x4_f32 (bit-exact fp32) -- but
+// the reduction index is ordered (16-channel block, tap, channel-in-block) and a K-chunk is
+// "one tap x 16 consecutive channels".  Consequences:
 //
-//   * gathered slab B: all 16 rows of a chunk share the tap, so a lane evaluates its voxel's
-//     validity bit ONCE per chunk and builds one voffset (or 0xFFFFFFFF, which the buffer
-//     range check turns into the zero padding); the 16 rows differ only by channel, which
-//     goes into the buffer load's scalar offset operand.  8 `buffer_load_dword` per lane per
-//     chunk cost 4 VALU in total (the generic kernel spends ~6 per load).
-//   * weight panel A: the weights are re-packed once per call into Wp[tap][channel][m]
-//     (m contiguous, padded to whole tiles and zero-filled), so a chunk's 16 x BM panel is a
-//     plain 2-D block: 16-B global loads, 16-B LDS stores, no transposition, no masks.
-//     Packing reads + writes the weight tensor once (<= 42 MB for the largest layer,
-//     ~10 us) against >= 0.3 ms of convolution.
-//   * no row-decode table, no per-row v_readfirstlane: the chunk -> (tap, channel block)
-//     walk lives in SGPRs.
+//   * gathered slab B: all 16 rows of a chunk share the tap, so a lane tests its voxel's
+//     tap-validity bit ONCE per chunk and builds one voffset (or 0xFFFFFFFF, which the buffer
+//     descriptor's range check turns into the zero padding: no branch, no select); the 16 rows
+//     differ only by channel, which goes into the buffer load's scalar offset operand.  The 9
+//     taps of a channel block are consecutive chunks, so its rows stay hot in L1/L2 (HBM read
+//     traffic is 1.05-1.07x the compulsory bytes, profiles/r01_s1_hbm_traffic.json).
+//   * weight panel A: the weights are re-packed once per call into Wp[block][tap][16][m]
+//     (m contiguous, padded to whole tiles, zero-filled), so a chunk's 16 x BM panel is a plain
+//     2-D block.  Packing reads + writes the weight tensor once (<= 42 MB, ~10 us).
+//   * both operands go global -> LDS by LDS-DMA (`buffer_load_dword ... lds` per 64-voxel k-row
+//     segment, `global_load_lds_dwordx4` for the panel): no staging VGPRs, no ds_write; the
+//     kernel fits 4 waves per SIMD (<= 128 VGPRs) and its only LDS instructions are the MFMA
+//     fragment reads, fetched one k-step ahead of the MFMA chain that consumes them.
+//   * epilogue: when the output is voxel-contiguous for the launch, the BM x BN tile is transposed
+//     through the (now free) staging LDS and stored as whole 512-B channel rows with 16-B lanes;
+//     the same pass can emit BatchNorm partial statistics (sum, sum of squares per channel and
+//     column tile) so the following BatchNorm needs no pass of its own over the activations.
+//   * launches that would under-fill the 1024 resident workgroups (layer3/4: 2x7x7 voxels) cut the
+//     K range into parts; parts write partial slabs that a second kernel adds in fixed order.
 //
 // Used for every layer whose gathered tensor has >= 16 channels and at most 31 taps; the
-// 3-channel 7x7 stems stay on the generic kernel.
+// 3-channel 7x7 stems stay on conv_igemm.hip.
 #include <stdlib.h>
 #include "conv_params.h"
 
@@ -52,202 +59,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, cons
     }
 }
 
-// NB = 16-channel blocks per K-chunk (BK = 16*NB rows between two barriers)
-template <int TM, int TN, int WGM, int WGN, int NB>
-__global__ __launch_bounds__(256) void conv_tap_kernel(IgemmParams prm, const float* __restrict__ Wp,
-                                                       const float* __restrict__ G, const float* __restrict__ bias,
-                                                       float* __restrict__ C, int tiles_m, int Mp, int nblk) {
-    constexpr int BM = 16 * TM * WGM;
-    constexpr int BN = 16 * TN * WGN;
-    constexpr int BK = 16 * NB;
-    constexpr int LDA = LdPad<BM>::value;
-    constexpr int LDB = LdPad<BN>::value;
-    constexpr int NT = 256;
-    static_assert(WGM * WGN == 4, "4 waves per workgroup");
-    static_assert(BN == 64 || BN == 128 || BN == 256, "BN must divide the workgroup");
-    static_assert(BM % 4 == 0 && LDA % 4 == 0, "16-B weight stores");
-    static_assert(16 % (NT / BN) == 0, "a staging pass never straddles two channel blocks");
-    constexpr int BROWS = NT / BN;
-    constexpr int BPASS = BK / BROWS;
-    constexpr int AQ = BM / 4;                           // float4 per k-row of the weight panel
-    constexpr int AVPASS = (BK * AQ + NT - 1) / NT;
-    constexpr unsigned OOB = 0xFFFFFFFFu;
-
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
-    __shared__ int tapoff[32];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = sgpr(tid >> 6);
-    const int wm0 = (wave / WGN) * (16 * TM);
-    const int wn0 = (wave % WGN) * (16 * TN);
-    const int tile = xcd_tile(gridDim.x, blockIdx.x);
-    const int m0 = (tile % tiles_m) * BM;
-    const int n0 = (tile / tiles_m) * BN;
-
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, prm.g_bytes, 0x00020000);
-
-    // byte offset of each tap inside the gathered tensor (signed; dgrad walks backwards)
-    if (tid < prm.taps) {
-        const int jt = tid / prm.nHW;
-        const int r = tid - jt * prm.nHW;
-        const int jh = r / prm.nW;
-        const int jw = r - jh * prm.nW;
-        tapoff[tid] = 4 * prm.dir * (jt * prm.gHW + jh * prm.gW + jw);
-    }
-
-    // ---- per-thread gather column: voxel -> base byte offset + tap-validity bits -----------
-    const int bcol = tid % BN;
-    const int brow0 = sgpr(tid / BN);
-    int base_bytes = 0;
-    unsigned vmask = 0;
-    {
-        const int p = n0 + bcol;
-        if (p < prm.P) {
-            const int n = p / prm.cS;
-            int r = p - n * prm.cS;
-            const int ct = r / prm.cHW;
-            r -= ct * prm.cHW;
-            const int ch = r / prm.cW;
-            const int cw = r - ch * prm.cW;
-            const int t0 = ct * prm.gsT + prm.goT, h0 = ch * prm.gsH + prm.goH, w0 = cw * prm.gsW + prm.goW;
-            base_bytes = 4 * (n * prm.gC * prm.gS + t0 * prm.gHW + h0 * prm.gW + w0);
-            unsigned mw = 0, mh = 0, mt = 0;
-            for (int j = 0; j < prm.nW; ++j) mw |= ((unsigned)(w0 + prm.dir * j) < (unsigned)prm.gW) << j;
-            for (int j = 0; j < prm.nH; ++j) mh |= ((unsigned)(h0 + prm.dir * j) < (unsigned)prm.gH) << j;
-            for (int j = 0; j < prm.nT; ++j) mt |= ((unsigned)(t0 + prm.dir * j) < (unsigned)prm.gT) << j;
-            int tap = 0;
-            for (int a = 0; a < prm.nT; ++a)
-                for (int b = 0; b < prm.nH; ++b)
-                    for (int c = 0; c < prm.nW; ++c, ++tap)
-                        vmask |= (((mt >> a) & (mh >> b) & (mw >> c)) & 1u) << tap;
-        }
-    }
-
-    // ---- weight panel: this thread's float4 slots (fixed for the whole kernel) --------------
-    const float* a_src[AVPASS];
-    int a_dst[AVPASS];
-#pragma unroll
-    for (int j = 0; j < AVPASS; ++j) {
-        // slots beyond the panel wrap around: a few threads stage one slot twice (same value,
-        // same LDS address) instead of branching -- a conditional here sends `areg` to scratch
-        const int e = (tid + NT * j) % (BK * AQ);
-        const int r = e / AQ, c4 = e % AQ;
-        a_src[j] = Wp + (size_t)r * Mp + m0 + 4 * c4;
-        a_dst[j] = r * LDA + 4 * c4;
-    }
-    const size_t a_chunk_stride = (size_t)BK * Mp;
-    const int ch_bytes = 4 * prm.gS;                     // one channel of the gathered tensor
-
-    float breg[BPASS];
-    f32x4 areg[AVPASS];       // native vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
-
-    const int nblocks = (prm.K > 0) ? prm.taps * nblk : 0;      // 16-channel blocks, (channel block, tap) order
-    const int nchunks = (nblocks + NB - 1) / NB;
-
-    // block index -> (tap, channel block); the walk stays in SGPRs
-    int ld_tap = 0, ld_cb = 0;
-    auto load_chunk = [&](int chunk) {
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            constexpr int JB = 16 / BROWS;                     // staging passes per 16-row block
-            const bool live = (chunk * NB + blk) < nblocks;    // a trailing half-chunk is zero
-            const int tap = live ? ld_tap : 0;
-            const int toff = sgpr(tapoff[tap]);
-            const unsigned ok = live ? ((vmask >> tap) & 1u) : 0u;
-            const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);   // padded tap -> 0xFFFFFFFF -> 0.0f
-            const int ci0 = ld_cb * 16;
-            if (ci0 + 16 <= prm.gC) {
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    const int ci = ci0 + brow0 + BROWS * j;
-                    breg[blk * JB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)voff, ci * ch_bytes, 0));
-                }
-            } else {                                           // last channel block of a tap: rows >= gC are zero
-#pragma unroll
-                for (int j = 0; j < JB; ++j) {
-                    const int ci = ci0 + brow0 + BROWS * j;
-                    const unsigned v = ci < prm.gC ? voff : OOB;
-                    breg[blk * JB + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0));
-                }
-            }
-            if (live) { if (++ld_tap == prm.taps) { ld_tap = 0; ++ld_cb; } }
-        }
-#pragma unroll
-        for (int j = 0; j < AVPASS; ++j)
-            areg[j] = *reinterpret_cast<const f32x4*>(a_src[j] + (size_t)chunk * a_chunk_stride);
-    };
-
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < BPASS; ++j) Bs[buf][(brow0 + BROWS * j) * LDB + bcol] = breg[j];
-#pragma unroll
-        for (int j = 0; j < AVPASS; ++j) *reinterpret_cast<f32x4*>(&As[buf][a_dst[j]]) = areg[j];
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // Pipeline (per chunk c, LDS double-buffered, one barrier):
-    //   [regs of chunk c+1 -> LDS]  [global loads of chunk c+2 -> regs]  [MFMAs of chunk c]  barrier
-    // The staged registers were loaded a whole chunk earlier, so their vmcnt wait is free and
-    // nothing is outstanding when a wave reaches the barrier.
-    __syncthreads();                      // tapoff visible
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-        if (nchunks > 1) load_chunk(1);
-    }
-    __syncthreads();
-
-    const int frag_row = lane >> 4;
-    const int frag_col = lane & 15;
-    constexpr int NH = BK / 8;            // 8-row half blocks: fragments are fetched one half ahead
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int cur = ch & 1;
-        if (ch + 1 < nchunks && !(prm.debug & 2)) store_chunk(cur ^ 1);
-        if (ch + 2 < nchunks && !(prm.debug & 1)) load_chunk(ch + 2);
-
-        const float* as = &As[cur][0];
-        const float* bs = &Bs[cur][0];
-        float a[2][2][TM], b[2][2][TN];
-        auto fetch = [&](int h, int slot) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[slot][kk][i] = as[((2 * h + kk) * 4 + frag_row) * LDA + wm0 + 16 * i + frag_col];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[slot][kk][j] = bs[((2 * h + kk) * 4 + frag_row) * LDB + wn0 + 16 * j + frag_col];
-            }
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            if (h + 1 < NH) fetch(h + 1, (h + 1) & 1);
-            // the next half's ds_reads are issued ahead of this half's MFMA chain (hipcc otherwise
-            // sinks each read next to its first use and waits lgkmcnt(0) every few MFMAs)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h & 1][kk][i], b[h & 1][kk][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!(prm.debug & 4)) __syncthreads();
-    }
-
-    store_tiles<TM, TN>(prm, acc, m0 + wm0, n0 + wn0, lane, bias, C);
-}
-
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant: the gathered slab and the weight panel go global -> LDS directly
+// Staging: the gathered slab and the weight panel go global -> LDS directly
 // (`buffer_load_dword ... lds` per k-row, `global_load_lds_dwordx4` for the panel): no staging
 // VGPRs, no ds_write, so the register budget drops under 128 (4 waves per SIMD) and the only
 // LDS instructions left are the MFMA fragment reads.  The LDS destination of a DMA is
@@ -513,30 +326,15 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     constexpr int BN = 16 * TN * WGN;
     const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN) * (prm.ksplit > 1 ? prm.ksplit : 1);
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
-    int nb = 1, dma = 1;
-    if (const char* e = getenv("ZSV_CONV_NB")) nb = atoi(e);
-    if (const char* e = getenv("ZSV_CONV_DMA")) dma = atoi(e);
-    if (prm.ksplit > 1 && dma == 0) dma = 1;         // split-K lives in the DMA kernel
-    if (dma == 1) {
-        if constexpr (TM == 9 && TN == 2) {
-            if (prm.dir == 1 && prm.taps == 9 && nblk == 4 && prm.ksplit <= 1 && !getenv("ZSV_NO_SPECIAL")) {
-                hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1, 4, 9>), dim3((unsigned)blocks), dim3(256), 0,
-                                   stream, prm, Wp, G, bias, C, tiles_m, Mp, nblk);
-                return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
-            }
+    if constexpr (TM == 9 && TN == 2) {
+        if (prm.dir == 1 && prm.taps == 9 && nblk == 4 && prm.ksplit <= 1) {
+            hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1, 4, 9>), dim3((unsigned)blocks), dim3(256), 0,
+                               stream, prm, Wp, G, bias, C, tiles_m, Mp, nblk);
+            return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
         }
-        hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
-                           Wp, G, bias, C, tiles_m, Mp, nblk);
     }
-    else if (dma == 2)
-        hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
-                           Wp, G, bias, C, tiles_m, Mp, nblk);
-    else if (nb == 2)
-        hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp,
-                           G, bias, C, tiles_m, Mp, nblk);
-    else
-        hipLaunchKernelGGL((conv_tap_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp,
-                           G, bias, C, tiles_m, Mp, nblk);
+    hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp, G,
+                       bias, C, tiles_m, Mp, nblk);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 
@@ -575,7 +373,6 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     int cfg, tiles_m, Mp, nblk, Cpad;
     tap_layout(prm_in, cfg, tiles_m, Mp, nblk, Cpad);
     IgemmParams prm = prm_in;
-    if (const char* e = getenv("ZSV_CONV_DEBUG")) prm.debug = atoi(e);
     if (prm.ksplit < 1 || !slabs) prm.ksplit = 1;
     // the transposing epilogue needs 4 consecutive voxels of a launch column group to be 4
     // consecutive, 16-B aligned floats of one clip

@@ -52,7 +52,6 @@ struct WgradParams {
     int sT, sH, sW, pT, pH, pW;
     int chunks_per_slice;   // 32-voxel chunks handled by one slice
     unsigned x_bytes, dy_bytes;
-    int debug;              // timing experiments (ZSV_WGRAD_DEBUG): 1 skip global loads, 2 skip LDS stores
 };
 
 template <int TM, int TN, int WGM, int WGN, bool AV4, int BP>      // BP = voxels per chunk (32 or 16)
@@ -416,8 +415,6 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.gS);
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
-    p.debug = 0;
-    if (const char* e = getenv("ZSV_WGRAD_DEBUG")) p.debug = atoi(e);
 
     const bool av4 = (p.oS % 4 == 0) && (p.P >= 4) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
     const int tiles_mn = pl.tiles_m * pl.tiles_n;
