@@ -340,3 +340,56 @@ def test_fused_multi_tensor_adam_matches_torch_adam():
     assert torch.equal(dev_p[-1].cpu(), ref_p[-1].detach())
     sd = dev_opt.state_dict()["state"]
     assert set(sd[0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd[0]["step"]) == 3.0
+
+
+def _rand_geometry(rng):
+    k = tuple(int(v) for v in rng.choice([1, 3, 5, 7], size=3, p=[0.35, 0.45, 0.1, 0.1]))
+    s = tuple(int(v) for v in rng.choice([1, 2, 3], size=3, p=[0.6, 0.3, 0.1]))
+    p = tuple(int(rng.integers(0, kk // 2 + 1)) for kk in k)
+    dims = tuple(int(rng.integers(max(1, kk - 2 * pp), max(2, kk - 2 * pp) + 9)) for kk, pp in zip(k, p))
+    cin = int(rng.choice([1, 3, 5, 16, 17, 32, 48, 70]))
+    cout = int(rng.choice([1, 2, 16, 45, 64, 80, 150]))
+    n = int(rng.integers(1, 4))
+    return n, cin, cout, k, s, p, dims
+
+
+def test_conv3d_random_geometries():
+    """Fuzz over kernel / stride / padding / channel counts (incl. 1-channel, non-multiples of 16,
+    voxel counts that are not multiples of 4, strides > kernel): forward, dgrad, wgrad vs fp64."""
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(99)
+    done = 0
+    while done < 40:
+        n, cin, cout, k, s, p, dims = _rand_geometry(rng)
+        if any((d + 2 * pp - kk) < 0 for d, pp, kk in zip(dims, p, k)):
+            continue
+        x = torch.randn(n, cin, *dims, generator=g)
+        wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+        use_bias = bool(rng.integers(0, 2))
+        b = torch.randn(cout, generator=g) if use_bias else None
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        br = b.double().requires_grad_() if use_bias else None
+        yr = F.conv3d(xr, wr, br, stride=s, padding=p)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy.double())
+        xg, wg = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+        bg = b.to(DEV).requires_grad_() if use_bias else None
+        tag = f"n{n} c{cin}->{cout} k{k} s{s} p{p} in{dims}"
+        yg = ops.conv3d(xg, wg, bg, s, p)
+        close(yg, yr, what=tag + " fwd")
+        yg.backward(dy.to(DEV))
+        close(xg.grad, xr.grad, what=tag + " dgrad")
+        close(wg.grad, wr.grad, rtol=5e-5, what=tag + " wgrad")
+        if use_bias:
+            close(bg.grad, br.grad, what=tag + " dbias")
+        done += 1
+
+
+def test_batchnorm_and_pool_edge_shapes():
+    g = torch.Generator().manual_seed(17)
+    for shape in [(1, 1, 1, 1, 2), (2, 3, 1, 1, 1), (1, 260, 1, 3, 3), (5, 2, 3, 5, 7)]:
+        x = torch.randn(*shape, generator=g)
+        ref = F.batch_norm(x.double(), None, None, None, None, training=True)
+        out = ops.batch_norm_act(x.to(DEV), None, None, None, None, None, True, 0.1, 1e-5, False)
+        close(out, ref, rtol=1e-4, what=f"bn {shape}")
+        close(ops.mean_pool(x.to(DEV)), x.double().mean(dim=(2, 3, 4)), what=f"meanpool {shape}")
