@@ -261,3 +261,32 @@ def test_full_size_batch22_forward_matches_oracle_and_is_deterministic():
         for i in (0, 7, 21):
             single = train.embed(model, xd[i:i + 1])
             assert rel_err(single.cpu().numpy(), full[i:i + 1].cpu().numpy()) < 1e-5
+
+
+def test_mc3_18_trunk_matches_oracle_trunk():
+    """resnet.mc3_18 (resnet.py:318-338) is not reachable through get_network but is part of the
+    module surface: 3x3x3 first stage, 1x3x3 (Conv3DNoTemporal, shortcut stride (1,s,s)) afterwards."""
+    from oracle import restatement as R
+    from zeroshotvideoclassification_amd import resnet
+    trunk = resnet.mc3_18()
+    ref = R.video_trunk("mc3_18")()
+    assert list(trunk.state_dict().keys()) == list(ref.state_dict().keys())
+    weights = synthetic.keyed_state_dict(ref.state_dict(), seed=2, bn_jitter=True)
+    trunk.load_state_dict(weights)
+    ref.load_state_dict(weights)
+    x = synthetic.synthetic_clips(2, 8, 48, seed=5).reshape(2, 3, 8, 48, 48)
+    ref.train()
+    pooled_ref, f_ref = ref(x)
+    pooled_ref.sum().backward()
+    trunk.to(DEV).train()
+    pooled, f = trunk(x.to(DEV))
+    pooled.sum().backward()
+    assert f.shape == f_ref.shape == (2, 512, 8, 3, 3)                # no temporal striding after stage 1
+    assert rel_err(pooled.detach().cpu().numpy(), pooled_ref.detach().numpy()) < TIGHT
+    assert rel_err(f.detach().cpu().numpy(), f_ref.detach().numpy()) < 5e-4
+    gr = dict(ref.named_parameters())
+    for k, p in trunk.named_parameters():
+        if gr[k].grad is None:
+            assert p.grad is None, k
+        else:
+            assert rel_l2(p.grad.cpu().numpy(), gr[k].grad.numpy()) < 5e-2, k
