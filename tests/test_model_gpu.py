@@ -290,3 +290,36 @@ def test_mc3_18_trunk_matches_oracle_trunk():
             assert p.grad is None, k
         else:
             assert rel_l2(p.grad.cpu().numpy(), gr[k].grad.numpy()) < 5e-2, k
+
+
+def test_training_loop_converges_like_the_oracle():
+    """30 Adam steps on a fixed synthetic batch (overfit): the loss must fall monotonically-ish, stay
+    finite, and track the CPU oracle's trajectory (same weights, same data, fp32) within 10 % per step
+    for the first steps and end below a fifth of where it started (sanity of the whole training path)."""
+    from oracle import restatement as R
+    opt = make_opt("r2plus1d_18")
+    model = network.get_network(opt)
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(weights)
+    oracle = R.oracle_network(opt)
+    oracle.load_state_dict(weights)
+    x = synthetic.synthetic_clips(4, 4, 32)
+    _, z = synthetic.synthetic_targets(4)
+    model.to(DEV).train()
+    oracle.train()
+    opt_g = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt_c = torch.optim.Adam(oracle.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss()
+    xd, zd = x.to(DEV), z.to(DEV)
+    lg, lc = [], []
+    for step in range(30):
+        _, l = train.train_step(model, opt_g, crit, xd, zd)
+        lg.append(l.item())
+        if step < 6:
+            _, l2 = R.train_step(oracle, opt_c, x, z)
+            lc.append(l2.item())
+    assert all(np.isfinite(lg))
+    assert abs(lg[0] / lc[0] - 1) < 1e-4
+    for a, b in zip(lg[:6], lc):
+        assert abs(a / b - 1) < 0.10, (lg[:6], lc)
+    assert lg[-1] < 0.2 * lg[0], lg
