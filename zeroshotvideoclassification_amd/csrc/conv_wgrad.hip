@@ -335,7 +335,10 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     if (const char* e = getenv("ZSV_WGRAD_CFG")) best = atoi(e) & 3;
     pl.cfg = best;
     pl.bm = bms[best];
+    // 128 columns per tile unless 64 wastes clearly less of the last tile (Kp = 432: 512 vs 448)
     pl.bn = 128;
+    if ((double)((pl.Kp + 63) / 64 * 64) * 1.12 < (double)((pl.Kp + 127) / 128 * 128)) pl.bn = 64;
+    if (const char* e = getenv("ZSV_WGRAD_BN")) pl.bn = atoi(e) == 64 ? 64 : 128;
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
     const int bp = wgrad_bp();
@@ -343,7 +346,11 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     // one full round of resident workgroups (256 CUs x LDS-limited 2-3 per CU): every workgroup
     // then runs start to finish concurrently and the slab traffic is minimal
-    const long resident = 256L * (pl.bm == 64 ? 3 : 2);
+    const long lds_bytes = (long)(pl.bm + pl.bn) * 34 * 4 * 2;
+    long per_cu = (160L * 1024) / lds_bytes;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const long resident = 256L * per_cu;
     long max_slices = (chunks * bp + 511) / 512;         // at least 512 voxels per slice
     if (max_slices < 1) max_slices = 1;
     if (max_slices > 1024) max_slices = 1024;
@@ -420,6 +427,14 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     const int tiles_mn = pl.tiles_m * pl.tiles_n;
     const dim3 grid((unsigned)(tiles_mn * pl.slices));
     float* out = (float*)workspace;
+    if (pl.bn == 64) {
+        switch (pl.cfg) {
+            case 0: wgrad_launch<9, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            case 1: wgrad_launch<8, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            case 2: wgrad_launch<4, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            default: wgrad_launch<5, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        }
+    } else
     switch (pl.cfg) {
         case 0: wgrad_launch<9, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
         case 1: wgrad_launch<4, 4, 2, 2>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
