@@ -287,14 +287,26 @@ struct TapCfg { int bm, bn; };
 static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}};
 
 static int tap_pick(const IgemmParams& prm) {
+    // Cost model: whole rounds of the 1024 resident workgroups (256 CUs x 4) times the tile's MACs,
+    // with a small penalty for the narrow row tiles (fewer MFMAs per fragment read).
+    static const double penalty[5] = {1.00, 1.00, 1.05, 1.08, 1.15};
     int best = 0;
     double best_w = 1e300;
     for (int i = 0; i < 5; ++i) {
         const double tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
         const double tn = (double)(((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn);
-        double w = tm * kTapCfgs[i].bm * tn * kTapCfgs[i].bn;
-        const double blocks = tm * tn;
-        if (blocks < 512) w *= (512.0 / (blocks < 1 ? 1 : blocks)) > 4.0 ? 4.0 : (512.0 / blocks);
+        const double tiles = tm * tn;
+        double w;
+        if (tiles > 1024.0) {
+            // workgroups are re-dispatched as slots free up, so a partial last round costs about
+            // half of what whole-round accounting would charge
+            const double r = tiles / 1024.0, rc = (double)(long)((tiles + 1023.0) / 1024.0);
+            w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i] * (1.0 + 0.5 * (rc - r) / r);
+        } else {
+            // under one round: padded work, favouring more (smaller) tiles -- split-K fills the rest
+            w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i];
+            if (tiles < 512.0) w *= (512.0 / tiles) > 4.0 ? 4.0 : (512.0 / tiles);
+        }
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
     if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % 5;
