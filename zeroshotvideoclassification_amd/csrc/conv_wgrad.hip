@@ -54,7 +54,10 @@ struct WgradParams {
     unsigned x_bytes, dy_bytes;
 };
 
-template <int TM, int TN, int WGM, int WGN, bool AV4, int BP>      // BP = voxels per chunk (32 or 16)
+// TWOTAP: every column tile of the launch spans at most two taps (true for all layers with >= 64
+// input channels): the padding test + gather offset are evaluated per TAP (2 per chunk) instead of
+// per 16-column block (8 per chunk).
+template <int TM, int TN, int WGM, int WGN, bool AV4, int BP, bool TWOTAP>      // BP = voxels per chunk (32 or 16)
 __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(WgradParams prm, const float* __restrict__ X,
                                                          const float* __restrict__ DY,
                                                          float* __restrict__ OUT, int tiles_m, int tiles_mn) {
@@ -93,7 +96,9 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
 
     // ---- the tile's 16-column blocks: tap (kt, kh, kw) and first channel, all wave-uniform ----
     int b_kt[NBLK], b_kh[NBLK], b_kw[NBLK], b_ci0[NBLK];
+    bool b_second[NBLK];                                 // TWOTAP: block uses the tile's second tap
     bool has_tail = false;
+    const int tap_first = min((n0 / 16) / prm.nblk, prm.taps - 1);
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
         const int blk = n0 / 16 + b;
@@ -106,7 +111,18 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
         const int kh = r / prm.kW;
         b_kt[b] = kt; b_kh[b] = kh; b_kw[b] = r - kh * prm.kW;
         b_ci0[b] = live ? cb * 16 : prm.Cin;            // dead block: every row is beyond Cin
+        b_second[b] = live && tap != tap_first;
         has_tail = has_tail || (b_ci0[b] + 16 > prm.Cin);
+    }
+    // the tile's (at most) two taps
+    int t2_kt[2], t2_kh[2], t2_kw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tap = min(tap_first + q, prm.taps - 1);
+        t2_kt[q] = tap / prm.kHW;
+        const int r = tap - t2_kt[q] * prm.kHW;
+        t2_kh[q] = r / prm.kW;
+        t2_kw[q] = r - t2_kh[q] * prm.kW;
     }
 
     // gather lanes: voxel column pcol, two rows per wave (row parity = half of the wave)
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
     bool ld_pv = false;
     int ld_t0 = 0, ld_h0 = 0, ld_w0 = 0, ld_xb = 0;
     unsigned ld_dyb = OOB;
+    unsigned ld_voff2[2] = {OOB, OOB};      // TWOTAP: gather offset (or OOB) of this voxel for the tile's two taps
     const float* ld_abase = DY;
     auto load_decode = [&](int chunk) {
         const unsigned p = (unsigned)(chunk * BP + pcol);
@@ -144,6 +161,14 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
         const unsigned ow = r1 - oh * prm.oW;
         ld_t0 = (int)ot * prm.sT - prm.pT; ld_h0 = (int)oh * prm.sH - prm.pH; ld_w0 = (int)ow * prm.sW - prm.pW;
         ld_xb = 4 * ((int)n * prm.gCS + ld_t0 * prm.gHW + ld_h0 * prm.gW + ld_w0) + half * ch_bytes;
+        if (TWOTAP) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = ld_pv && (unsigned)(ld_t0 + t2_kt[q]) < (unsigned)prm.gT &&
+                                (unsigned)(ld_h0 + t2_kh[q]) < (unsigned)prm.gH && (unsigned)(ld_w0 + t2_kw[q]) < (unsigned)prm.gW;
+                ld_voff2[q] = ok ? (unsigned)(ld_xb + 4 * (t2_kt[q] * prm.gHW + t2_kh[q] * prm.gW + t2_kw[q])) : OOB;
+            }
+        }
         if (AV4) {
             // 4 voxels of one clip (oS % 4 == 0); clamp instead of masking: rows >= M are never
             // stored, voxels >= P meet zeros from the gathered operand
@@ -156,9 +181,14 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
         }
     };
     auto load_b = [&](int b) {          // gathered rows of 16-column block b
-        const bool ok = ld_pv && (unsigned)(ld_t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(ld_h0 + b_kh[b]) < (unsigned)prm.gH &&
-                        (unsigned)(ld_w0 + b_kw[b]) < (unsigned)prm.gW;
-        const unsigned voff = ok ? (unsigned)(ld_xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
+        unsigned voff;
+        if (TWOTAP) {
+            voff = b_second[b] ? ld_voff2[1] : ld_voff2[0];
+        } else {
+            const bool ok = ld_pv && (unsigned)(ld_t0 + b_kt[b]) < (unsigned)prm.gT && (unsigned)(ld_h0 + b_kh[b]) < (unsigned)prm.gH &&
+                            (unsigned)(ld_w0 + b_kw[b]) < (unsigned)prm.gW;
+            voff = ok ? (unsigned)(ld_xb + 4 * (b_kt[b] * prm.gHW + b_kh[b] * prm.gW + b_kw[b])) : OOB;
+        }
         // rows of block b handled by this thread: ci0 + RW*wave + half + RPP*jj
 #pragma unroll
         for (int jj = 0; jj < PB; ++jj) {
@@ -305,10 +335,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     }
 }
 
-static int wgrad_bp() {
-    if (const char* e = getenv("ZSV_WGRAD_BP")) return atoi(e) == 16 ? 16 : 32;
-    return 32;
-}
+static int wgrad_bp() { return 32; }
 
 struct WgradPlan {
     int cfg;        // 0: 144x128, 1: 128x128, 2: 64x128, 3: 80x128
@@ -373,16 +400,22 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
 }
 
 template <int TM, int TN, int WGM, int WGN>
-static void wgrad_launch(const WgradParams& p, bool av4, dim3 grid, hipStream_t stream, const float* x, const float* dy,
-                         float* out, int tiles_m, int tiles_mn) {
-    const int bp = wgrad_bp();
-    if (bp == 16) {
-        if (av4) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true, 16>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false, 16>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
-    } else {
-        if (av4) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, true, 32>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, false, 32>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn);
+static void wgrad_launch(const WgradParams& p, bool av4, bool twotap, dim3 grid, hipStream_t stream, const float* x,
+                         const float* dy, float* out, int tiles_m, int tiles_mn) {
+#define ZSV_WG(A, T) hipLaunchKernelGGL((conv_wgrad_kernel<TM, TN, WGM, WGN, A, 32, T>), grid, dim3(256), 0, stream, p, x, dy, out, tiles_m, tiles_mn)
+    if (av4) { if (twotap) ZSV_WG(true, true); else ZSV_WG(true, false); }
+    else { if (twotap) ZSV_WG(false, true); else ZSV_WG(false, false); }
+#undef ZSV_WG
+}
+
+// every column tile of `bn` columns spans at most two taps?
+static bool wgrad_two_taps(int taps, int nblk, int bn) {
+    const int nb = bn / 16, total = taps * nblk;
+    for (int b0 = 0; b0 < total; b0 += nb) {
+        const int last = (b0 + nb - 1 < total ? b0 + nb - 1 : total - 1);
+        if (last / nblk - b0 / nblk > 1) return false;
     }
+    return true;
 }
 
 }  // namespace zsv
@@ -424,22 +457,23 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
 
     const bool av4 = (p.oS % 4 == 0) && (p.P >= 4) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+    const bool twotap = wgrad_two_taps(p.taps, pl.nblk, pl.bn) && !getenv("ZSV_WGRAD_NO_TWOTAP");
     const int tiles_mn = pl.tiles_m * pl.tiles_n;
     const dim3 grid((unsigned)(tiles_mn * pl.slices));
     float* out = (float*)workspace;
     if (pl.bn == 64) {
         switch (pl.cfg) {
-            case 0: wgrad_launch<9, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-            case 1: wgrad_launch<8, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-            case 2: wgrad_launch<4, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-            default: wgrad_launch<5, 1, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            case 0: wgrad_launch<9, 1, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            case 1: wgrad_launch<8, 1, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            case 2: wgrad_launch<4, 1, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+            default: wgrad_launch<5, 1, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
         }
     } else
     switch (pl.cfg) {
-        case 0: wgrad_launch<9, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-        case 1: wgrad_launch<4, 4, 2, 2>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-        case 2: wgrad_launch<4, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
-        default: wgrad_launch<5, 2, 1, 4>(p, av4, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        case 0: wgrad_launch<9, 2, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        case 1: wgrad_launch<4, 4, 2, 2>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        case 2: wgrad_launch<4, 2, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
+        default: wgrad_launch<5, 2, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
     }
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const long n = (long)p.M * p.taps * pl.Cpad;
