@@ -134,6 +134,23 @@ def test_checkpoint_round_trip_with_module_prefix(tmp_path):
         assert torch.equal(a, b), k
 
 
+def test_save_checkpoint_and_load_weights_helpers(tmp_path):
+    from zeroshotvideoclassification_amd import train
+    model = network.get_network(make_opt("r3d_18"))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=5))
+    path = str(tmp_path / "checkpoint.pth.tar")
+    train.save_checkpoint(model, path, opt={"network": "r3d_18"}, accuracy=12.5)
+    ckpt = torch.load(path, weights_only=False)
+    assert set(ckpt) == {"state_dict", "opt", "accuracy"} and ckpt["accuracy"] == 12.5
+    assert all(k.startswith("module.") for k in ckpt["state_dict"])
+    ckpt["state_dict"]["module.not_in_model"] = torch.zeros(1)            # dropped by the key intersection
+    torch.save(ckpt, path)
+    other = network.get_network(make_opt("r3d_18"))
+    assert train.load_weights(other, path) == len(model.state_dict())
+    for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_synthetic_inputs_follow_the_input_contract():
     x = synthetic.synthetic_clips(2, 4, 16)
     assert x.shape == (2, 1, 3, 4, 16, 16) and x.dtype == torch.float32

@@ -11,6 +11,10 @@ does not stall the queue.
 ``evaluate`` / ``compute_accuracy`` restate main.py:224-325: eval-mode forward under
 ``no_grad``, cosine nearest class in the 300-d embedding space, top-1 / top-5, and the ten
 seeded half-class splits.
+
+``load_weights`` / ``save_checkpoint`` keep the reference's checkpoint format (main.py:114-124,
+361-365): ``{'state_dict' ('module.'-prefixed keys), 'opt', 'accuracy'}``, loaded by key
+intersection, so checkpoints move between the two implementations unchanged.
 """
 from __future__ import annotations
 
@@ -19,6 +23,29 @@ from typing import Iterable, Optional, Sequence, Tuple
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+
+_PREFIX = "module."       # nn.DataParallel's prefix in saved checkpoints (main.py:116,126,363)
+
+
+def load_weights(model: torch.nn.Module, path: str) -> int:
+    """main.py:114-124: strip the ``module.`` prefix, keep the keys the model has, load the rest
+    from the model itself.  Returns the number of tensors taken from the checkpoint."""
+    weights = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
+    own = getattr(model, "module", model)
+    model_dict = own.state_dict()
+    j = len(_PREFIX)
+    weights = {k[j:]: v for k, v in weights.items() if k[j:] in model_dict}
+    model_dict.update(weights)
+    own.load_state_dict(model_dict)
+    return len(weights)
+
+
+def save_checkpoint(model: torch.nn.Module, path: str, opt=None, accuracy: float = 0.0) -> None:
+    """main.py:361-365: the saved keys carry the ``module.`` prefix whether or not the model is wrapped."""
+    own = getattr(model, "module", model)
+    state = {_PREFIX + k: v.detach().cpu() for k, v in own.state_dict().items()}
+    torch.save({"state_dict": state, "opt": opt, "accuracy": accuracy}, path)
 
 
 def embed(model: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
