@@ -161,6 +161,33 @@ int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
 int zsv_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* ---- bf16 inference path (BASELINE config 5: 32-frame bf16 eval, main.py:224-313) ------------ */
+/* Forward-only convolution with eval-mode BatchNorm folded in:
+ *     y = relu?( conv3d(x, w * scale[cout]) + shift[cout] (+ residual) )
+ * = Conv3d -> BatchNorm3d.eval() -> ReLU (resnet.py:40-52,94-98) and `out += residual; relu`
+ * (resnet.py:110-111); scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale.
+ * bf16 x bf16 products accumulate in fp32 (v_mfma_f32_16x16x32_bf16).
+ *
+ * Activations are channels-last bf16: [N][T][H][W][Cp] with Cp = zsv_bf16_channel_pitch(C)
+ * (C rounded up to 32; pad channels are written as zero).  A clip (Cin <= 4) is the exception: it is
+ * stored [N][T][Hi][Wi][4] with the H/W zero border already materialised (zsv_clip_to_bf16), so its
+ * conv desc carries the padded Hi/Wi and pH = pW = 0, and needs (Wo-1)*sW + 8 <= Wi.
+ * `blob` = the packed bf16 weights followed by the fp32 shifts (zsv_conv3d_bf16_blob_bytes), built
+ * once per layer by zsv_conv3d_bf16_pack (scale / shift may be NULL = 1 / 0: plain conv or bias).
+ * `residual` (may be NULL) and y have the output's layout. */
+int32_t zsv_bf16_channel_pitch(int32_t channels);
+size_t zsv_conv3d_bf16_blob_bytes(const zsv_conv_desc* d);
+int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* scale, const float* shift,
+                         void* blob, void* stream);
+int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual,
+                        int fuse_relu, void* y, void* stream);
+/* (N, C<=4, T, H, W) fp32 clip -> [N][T][Hp][Wp][4] bf16, the frame placed at (padH, padW) inside a
+ * zero border; Hp >= H + padH, Wp >= W + padW. */
+int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, int32_t padH,
+                     int32_t padW, int32_t Hp, int32_t Wp, void* out, void* stream);
+/* [N][S][Cp] bf16 -> (N, C) fp32 mean over the S voxels (resnet.py:251-254 avgpool + flatten). */
+int zsv_meanpool_bf16(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);
+
 /* ---- clip pre-processing ------------------------------------------------------ */
 /* The reference's transform chain (auxiliary/transforms.py:41-56): (u8/255 - 1)/2 and THWC->CTHW
  * (:116-117), bilinear resize of the short side to 128 with align_corners=False (:99-107), a

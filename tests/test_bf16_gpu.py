@@ -1,0 +1,184 @@
+"""bf16 inference path (BASELINE config 5): zsv_conv3d_bf16_fwd per layer against an fp64 CPU
+convolution of the SAME bf16-rounded operands, and the whole Bf16Engine against the fp32 oracle
+fixtures.
+
+Tolerances (written here because north_star's 1e-3 is the fp32 figure): a single layer differs from
+the exact result of its rounded operands only by fp32 accumulation order and the final rounding to
+bf16 (half an ulp = 2^-9 relative), so 2^-8 relative + 1e-3 absolute per element; end to end the
+bf16 activations of ~40 layers compound, and the 300-d unit-norm embedding is required to stay
+within 2e-2 (max abs, components are O(0.06)) and cosine >= 0.999 of the fp32 oracle's.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden, make_opt
+from zeroshotvideoclassification_amd import inference, network, ops, synthetic, train
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def to_ndhwc(x, pitch):
+    """(N,C,T,H,W) fp32 -> [N][T][H][W][pitch] bf16 (test-side layout change)."""
+    n, c, t, h, w = x.shape
+    out = torch.zeros((n, t, h, w, pitch), dtype=torch.bfloat16, device=x.device)
+    out[..., :c] = x.permute(0, 2, 3, 4, 1).to(torch.bfloat16)
+    return out
+
+
+def from_ndhwc(y, c):
+    return y[..., :c].permute(0, 4, 1, 2, 3).float()
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+CASES = [
+    # n, cin, cout, (t,h,w), kernel, stride, padding, residual, relu
+    (2, 64, 144, (4, 14, 14), (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True),     # S1-like, row tile 144 + zero-filled pitch
+    (2, 144, 64, (4, 14, 14), (3, 1, 1), (1, 1, 1), (1, 0, 0), True, True),      # T1-like + residual, K pitch 160
+    (1, 64, 230, (4, 16, 16), (1, 3, 3), (1, 2, 2), (0, 1, 1), False, True),     # strided spatial
+    (1, 230, 128, (6, 8, 8), (3, 1, 1), (2, 1, 1), (1, 0, 0), False, False),     # strided temporal, no relu
+    (3, 64, 128, (4, 12, 12), (1, 1, 1), (2, 2, 2), (0, 0, 0), False, False),    # shortcut 1x1x1
+    (1, 45, 64, (5, 9, 11), (3, 1, 1), (1, 1, 1), (1, 0, 0), False, True),       # T0: 45 -> pitch 64
+    (1, 128, 288, (3, 10, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1), True, True),     # r3d-style 3x3x3
+    (1, 512, 1152, (2, 7, 7), (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True),     # layer4 width
+    (1, 921, 512, (2, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0), True, True),       # 921 -> pitch 928, ragged voxel tile
+    (5, 32, 33, (1, 3, 3), (1, 3, 3), (1, 1, 1), (0, 1, 1), False, False),       # tiny, Cout just over one chunk
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
+def test_conv_bf16_matches_fp64_of_rounded_operands(case):
+    n, cin, cout, (t, h, w), k, s, p, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = bf16_round(torch.randn((n, cin, t, h, w), generator=g))
+    wgt = torch.randn((cout, cin) + k, generator=g) / np.sqrt(cin * np.prod(k))
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv3d(x.double(), bf16_round(wgt * scale.view(-1, 1, 1, 1, 1)).double(), stride=s, padding=p)
+    ref = ref + shift.double().view(1, -1, 1, 1, 1)
+    res = None
+    if use_res:
+        res = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp_min(0)
+
+    d = ops.conv_desc(x.shape, wgt.shape, s, p)
+    blob = inference.pack_conv(d, wgt.to(DEV), scale.to(DEV), shift.to(DEV))
+    xb = to_ndhwc(x.to(DEV), inference.channel_pitch(cin))
+    rb = to_ndhwc(res.to(DEV), inference.channel_pitch(cout)) if use_res else None
+    y = inference.conv_bf16(d, xb, blob, rb, relu)
+    assert y.shape[-1] == inference.channel_pitch(cout)
+    assert torch.count_nonzero(y[..., cout:]) == 0, "pad channels must be written as zero"
+    got = from_ndhwc(y, cout).cpu().double()
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-3
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst ratio {(err / tol).max().item():.2f}"
+
+
+@pytest.mark.parametrize("kernel,stride,padding", [((1, 7, 7), (1, 2, 2), (0, 3, 3)), ((3, 7, 7), (1, 2, 2), (1, 3, 3))])
+def test_clip_convolution_folded_form(kernel, stride, padding):
+    """The stems (resnet.py:170,181): 3 channels, border materialised, kw folded into K."""
+    g = torch.Generator().manual_seed(11)
+    n, t, h, w, cout = 2, 4, 20, 24, 45
+    x = bf16_round(torch.rand((n, 3, t, h, w), generator=g) * 0.5 - 0.5)
+    wgt = torch.randn((cout, 3) + kernel, generator=g) / np.sqrt(3 * np.prod(kernel))
+    conv = torch.nn.Conv3d(3, cout, kernel, stride, padding, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(wgt)
+    bn = torch.nn.BatchNorm3d(cout)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    op = inference._ConvOp(conv.to(DEV), bn.to(DEV), relu=True)
+    pad_h, pad_w, hp, wp = op.input_border(h, w)
+    xb = inference.clip_to_bf16(x.to(DEV), pad_h, pad_w, hp, wp)
+    assert xb.shape == (n, t, hp, wp, 4)
+    wo = (w + 2 * padding[2] - kernel[2]) // stride[2] + 1
+    y = op(xb, wo=wo)
+    scale, shift = inference.fold_bn(bn, conv)
+    ref = F.conv3d(x.double(), bf16_round(wgt * scale.cpu().view(-1, 1, 1, 1, 1)).double(), stride=stride, padding=padding)
+    ref = (ref + shift.cpu().double().view(1, -1, 1, 1, 1)).clamp_min(0)
+    got = from_ndhwc(y, cout).cpu().double()
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-3).all()), f"max err {err.max().item():.3e}"
+
+
+def test_meanpool_bf16():
+    x = torch.randn((3, 2, 5, 7, 96), device=DEV).to(torch.bfloat16)
+    got = inference.meanpool_bf16(x, 70)
+    ref = x.float().mean(dim=(1, 2, 3))[:, :70]
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_rejects():
+    x = torch.zeros((1, 2, 4, 4, 64), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        inference.meanpool_bf16(x, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        inference.Bf16Engine(network.get_network(make_opt("r2plus1d_18")))
+    d = ops.conv_desc((1, 64, 2, 4, 4), (64, 64, 1, 3, 3), 1, (0, 1, 1))
+    blob = inference.pack_conv(d, torch.zeros((64, 64, 1, 3, 3), device=DEV), None, None)
+    with pytest.raises(RuntimeError, match="does not match"):
+        inference.conv_bf16(d, torch.zeros((1, 2, 4, 4, 32), dtype=torch.bfloat16, device=DEV), blob)
+
+
+def _model(name, seed, jitter=True):
+    if name == "mc3_18":            # not reachable through get_network's dispatch (network.py:24-44)
+        from zeroshotvideoclassification_amd import resnet
+        model = network.Model(resnet.mc3_18)
+    else:
+        model = network.get_network(make_opt(name))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=seed, bn_jitter=jitter))
+    return model.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", ["r2plus1d_18", "r3d_18", "mc3_18"])
+def test_engine_matches_fp32_eval_forward(name):
+    """Same weights, eval mode: bf16 engine vs the fp32 HIP path (itself pinned to the oracle)."""
+    model = _model(name, seed=7)
+    x = synthetic.synthetic_clips(3, 8, 64).to(DEV)
+    with torch.no_grad():
+        ref, _ = model(x)
+    emb, second = inference.Bf16Engine(model)(x)
+    assert second is None and emb.shape == ref.shape and emb.dtype == torch.float32
+    assert torch.allclose(emb.norm(dim=1), torch.ones(3, device=DEV), atol=1e-5)
+    cos = (emb * ref).sum(dim=1)
+    assert cos.min().item() >= 0.999, cos
+    assert (emb - ref).abs().max().item() <= 2e-2
+
+
+def test_engine_matches_oracle_fixture_t32():
+    """Config E fixture: 32-frame eval-mode embedding from the fp32 CPU oracle (tests/golden)."""
+    from test_model_gpu import build
+    g, model, _ = build("r2plus1d_jitter")
+    model.eval()
+    x32 = synthetic.synthetic_clips(1, 32, int(g["meta_size"]), seed=99).to(DEV)
+    emb, _ = inference.Bf16Engine(model)(x32)
+    ref = torch.from_numpy(g["emb_eval_t32_f32"]).to(DEV)
+    cos = (emb * ref).sum(dim=1)
+    assert cos.min().item() >= 0.999, cos
+    assert (emb - ref).abs().max().item() <= 2e-2
+
+
+def test_engine_ranking_agrees_with_fp32():
+    """Nearest-class ranking (main.py:316-325) from bf16 embeddings vs fp32 embeddings."""
+    model = _model("r2plus1d_18", seed=3)
+    x = synthetic.synthetic_clips(8, 8, 64, seed=99).to(DEV)
+    table = synthetic.class_table(101).to(DEV)
+    with torch.no_grad():
+        ref, _ = model(x)
+    emb, _ = inference.Bf16Engine(model)(x)
+    top_ref = train.cosine_ranking(ref, table)[:, :5]
+    top = train.cosine_ranking(emb, table)[:, :5]
+    assert (top[:, 0] == top_ref[:, 0]).float().mean().item() >= 0.75
+    overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(top, top_ref)])
+    assert overlap >= 4.0

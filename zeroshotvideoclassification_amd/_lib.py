@@ -60,6 +60,12 @@ SIGNATURES = {
     "zsv_linear_dgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "zsv_linear_wgrad_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "zsv_linear_wgrad": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "zsv_bf16_channel_pitch": (c_int32, [c_int32]),
+    "zsv_conv3d_bf16_blob_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "zsv_conv3d_bf16_pack": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "zsv_conv3d_bf16_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P]),
+    "zsv_clip_to_bf16": (c_int, [_P] + [c_int32] * 9 + [_P, _P]),
+    "zsv_meanpool_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_clip_transform": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P, _P, _P]),
     "zsv_adam_multi": (c_int, [_P, c_int32, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
     "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),

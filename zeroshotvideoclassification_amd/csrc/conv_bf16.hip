@@ -1,0 +1,405 @@
+// conv_bf16.hip -- bf16 inference convolution (BASELINE config 5: 32-frame bf16 eval loop).
+//
+// Forward-only Conv3d with the eval-mode BatchNorm folded in (main.py:229 `model.eval()`):
+//     y = relu?( conv3d(x, w * scale[cout]) + shift[cout] (+ residual) )
+// which is what Conv3d -> BatchNorm3d(eval) -> ReLU (resnet.py:40-52,94-98) and the block tail
+// `out += residual; relu` (resnet.py:110-111) compute.  Products are bf16 x bf16 accumulated in
+// fp32 on v_mfma_f32_16x16x32_bf16; activations travel between layers in bf16.
+//
+// Layout (channels-last, so that the MFMA's 8 consecutive k elements are 16 contiguous bytes):
+//     activations  [N][T][H][W][Cp]  bf16, Cp = Cin rounded up to 32, pad channels are zero
+//     weights      Wp[q][Mp][32]     bf16, q = tap * (Cp/32) + chunk, rows padded to the row tile
+//     blob         Wp followed by Mp fp32 shifts
+// A clip (Cin = 3) uses the "folded" form: pixels are stored [N][T][Hp][Wp][4] with the H/W zero
+// padding materialised, and one K chunk of 32 is 8 consecutive pixels x 4 channels of one (kt, kh)
+// row, i.e. kw is folded into the chunk (taps = kT*kH, weights at k = 4*kw + c).
+//
+// Implicit GEMM: rows = produced channels, columns = output voxels, K = taps x Cp in chunks of 32.
+// One workgroup = 4 waves computes a (16*TM*WGM) x (16*TN*WGN) tile; per K chunk the A rows
+// (BM x 64 B, contiguous in Wp) and the B rows (one 64-byte channel segment per voxel, zero line for
+// padding taps) are staged through registers into a double-buffered, XOR-swizzled LDS image and read
+// back as ds_read_b128 fragments.
+#include <hip/hip_runtime.h>
+
+#include "conv_params.h"
+#include "zsv_common.h"
+#include "zsv_hip.h"
+
+namespace zsv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ u32x4 zsv_zero_line[8];      // 128 zero bytes: what a padding tap reads
+
+struct Bf16Params {
+    int M, Mp, CoutP;          // produced channels, packed rows (row tiles x BM), output channel pitch
+    int nq, nchunk;            // K chunks of 32: total and per tap
+    int kT, kH, kW;            // tap grid (kW = 1 in the folded form)
+    int sT, sH, sW;            // input elements per t / h / w step
+    long sN;                   // input elements per clip
+    int Ti, Hi, Wi;            // input extents (validity of a tap)
+    int ToHoWo, HoWo, Wo;
+    int strT, strH, strW, pT, pH, pW;
+    int P;                     // output voxels N*To*Ho*Wo
+    int tiles_m, tiles_n;
+    int relu;
+};
+
+// 16-byte slot swizzle of a 64-byte LDS row: ds_read_b128 serves lanes in the groups
+// {0-3,12-15,20-27},{4-11,16-19,28-31},... (MI355X_MICROARCH.md, LDS table); with slot ^= swz(row) the
+// 16 lanes of every group fall on 16 distinct slots of the 256-byte bank row.
+__device__ __forceinline__ int swz(int row) {
+    const int j = (row >> 2) & 3, g = j ^ (j >> 1);
+    return ((g & 1) << 1) | (g >> 1);
+}
+
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const __bf16* __restrict__ X,
+                                                           const __bf16* __restrict__ Wp,
+                                                           const float* __restrict__ shift,
+                                                           const __bf16* __restrict__ R, __bf16* __restrict__ Y) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int A_PIECES = BM * 4;                 // 16-byte pieces of one A stage
+    constexpr int NA = (A_PIECES + 255) / 256;
+    constexpr int NB = BN / 64;                      // voxel rows per thread
+    constexpr int STAGE = (BM + BN) * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int tm = tile % prm.tiles_m, tn = tile / prm.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-thread staging assignment -------------------------------------------------------
+    const int piece = tid & 3;
+    int b_base[NB], b_t0[NB], b_h0[NB], b_w0[NB], b_lds[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int r = (tid >> 2) + 64 * j;
+        const int p = n0 + r;
+        const bool pv = p < prm.P;
+        const int pp = pv ? p : 0;
+        const int n = pp / prm.ToHoWo;
+        int rem = pp - n * prm.ToHoWo;
+        const int to = rem / prm.HoWo;
+        rem -= to * prm.HoWo;
+        const int ho = rem / prm.Wo, wo = rem - ho * prm.Wo;
+        b_t0[j] = pv ? to * prm.strT - prm.pT : -0x100000;      // invalid voxel: every tap is out of range
+        b_h0[j] = ho * prm.strH - prm.pH;
+        b_w0[j] = wo * prm.strW - prm.pW;
+        b_base[j] = (int)(n * prm.sN) + b_t0[j] * prm.sT + b_h0[j] * prm.sH + b_w0[j] * prm.sW + piece * 8;
+        b_lds[j] = BM * 64 + r * 64 + ((piece ^ swz(r)) << 4);
+    }
+    int a_src[NA], a_lds[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int p = tid + 256 * j;
+        p = p < A_PIECES ? p : A_PIECES - 1;             // surplus threads repeat the last piece
+        a_src[j] = p * 8;
+        a_lds[j] = (p >> 2) * 64 + (((p & 3) ^ swz(p >> 2)) << 4);
+    }
+    const __bf16* wq = Wp + (size_t)m0 * 32;             // chunk q lives at + q*Mp*32
+    const size_t wq_step = (size_t)prm.Mp * 32;
+    const __bf16* zero = (const __bf16*)zsv_zero_line;
+
+    // uniform walk over (tap, chunk)
+    int kt = 0, kh = 0, kw = 0, cc = 0;
+    u32x4 areg[NA], breg[NB];
+    auto load_stage = [&]() {
+        const int tapoff = kt * prm.sT + kh * prm.sH + kw * prm.sW + cc * 32;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) areg[j] = *(const u32x4*)(wq + a_src[j]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const bool ok = (unsigned)(b_t0[j] + kt) < (unsigned)prm.Ti && (unsigned)(b_h0[j] + kh) < (unsigned)prm.Hi &&
+                            (unsigned)(b_w0[j] + kw) < (unsigned)prm.Wi;
+            const __bf16* src = ok ? X + (b_base[j] + tapoff) : zero;
+            breg[j] = *(const u32x4*)src;
+        }
+        wq += wq_step;
+        if (++cc == prm.nchunk) {
+            cc = 0;
+            if (++kw == prm.kW) {
+                kw = 0;
+                if (++kh == prm.kH) { kh = 0; ++kt; }
+            }
+        }
+    };
+    auto write_stage = [&](int buf) {
+        unsigned char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) *(u32x4*)(base + a_lds[j]) = areg[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *(u32x4*)(base + b_lds[j]) = breg[j];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    const int a_frag = wm * TM * 16 * 64 + frag_off;
+    const int b_frag = BM * 64 + wn * TN * 16 * 64 + frag_off;
+
+    load_stage();
+    write_stage(0);
+    __syncthreads();
+    for (int q = 0; q < prm.nq; ++q) {
+        const bool more = q + 1 < prm.nq;
+        if (more) load_stage();
+        const unsigned char* s = lds + (q & 1) * STAGE;
+        bf16x8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *(const bf16x8*)(s + b_frag + j * 1024);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x8 af = *(const bf16x8*)(s + a_frag + i * 1024);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) write_stage((q + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + shift (+ residual), relu, bf16, channels-last store ----------------------
+    // lane holds, per accumulator tile, 4 consecutive channels of one voxel = one 8-byte store
+    const int ch_lane = m0 + wm * TM * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+        if (col >= prm.P) continue;
+        const size_t row_off = (size_t)col * prm.CoutP;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ch = ch_lane + i * 16;
+            if (ch >= prm.CoutP) continue;
+            f32x4 v = acc[i][j] + *(const f32x4*)(shift + ch);
+            if (R != nullptr) {
+                const bf16x4 r = *(const bf16x4*)(R + row_off + ch);
+                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+            }
+            if (prm.relu) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            bf16x4 o;
+            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+            *(bf16x4*)(Y + row_off + ch) = o;
+        }
+    }
+    // channels between the last packed row and the pitch (e.g. 144 -> 160) stay zero
+    const int covered = prm.tiles_m * BM;
+    if (tm == prm.tiles_m - 1 && covered < prm.CoutP) {
+        const int per_col = (prm.CoutP - covered) >> 2;            // 8-byte pieces per voxel
+        for (int idx = tid; idx < BN * per_col; idx += 256) {
+            const int c = idx / per_col, k = idx - c * per_col;
+            const int col = n0 + c;
+            if (col < prm.P) *(u32x2*)(Y + (size_t)col * prm.CoutP + covered + 4 * k) = u32x2{0u, 0u};
+        }
+    }
+}
+
+// Wp[q][Mp][32] <- w[Cout][Cin][kT][kH][kW] * scale[cout]; then Mp fp32 shifts.
+__global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, __bf16* __restrict__ wp, float* __restrict__ shift_out,
+                                 int M, int Mp, int Cin, int taps, int nchunk, int kW, int folded, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < Mp) shift_out[idx] = (idx < M && shift != nullptr) ? shift[idx] : 0.f;
+    if (idx >= total) return;
+    const int k = (int)(idx & 31);
+    const long rq = idx >> 5;
+    const int row = (int)(rq % Mp);
+    const int q = (int)(rq / Mp);
+    float v = 0.f;
+    if (row < M) {
+        const float s = scale != nullptr ? scale[row] : 1.f;
+        if (folded) {                       // q = kt*kH + kh, k = 4*kw + c
+            const int kwi = k >> 2, c = k & 3;
+            if (kwi < kW && c < Cin) v = w[(((long)row * Cin + c) * taps + q) * kW + kwi] * s;
+        } else {
+            const int tap = q / nchunk, ci = (q - tap * nchunk) * 32 + k;
+            if (ci < Cin) v = w[((long)row * Cin + ci) * taps + tap] * s;
+        }
+    }
+    wp[idx] = (__bf16)v;
+}
+
+// (N,3,T,H,W) fp32 -> [N][T][Hp][Wp][4] bf16 with a zero border of (padH, padW) (and zero 4th channel)
+__global__ void clip_to_bf16_kernel(const float* __restrict__ x, int C, int T, int H, int W, int padH, int padW, int Hp,
+                                    int Wpix, long total, __bf16* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int wp = (int)(idx % Wpix);
+    long r = idx / Wpix;
+    const int hp = (int)(r % Hp);
+    r /= Hp;
+    const int t = (int)(r % T);
+    const long n = r / T;
+    const int h = hp - padH, wq = wp - padW;
+    bf16x4 o;
+    o[0] = o[1] = o[2] = o[3] = (__bf16)0.f;
+    if ((unsigned)h < (unsigned)H && (unsigned)wq < (unsigned)W) {
+        const long S = (long)T * H * W;
+        const float* src = x + n * C * S + ((long)t * H + h) * W + wq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) o[c] = (__bf16)src[c * S];
+    }
+    *(bf16x4*)(out + idx * 4) = o;
+}
+
+// [N][S][Cp] bf16 -> (N, C) fp32 mean over S (resnet.py:251 AdaptiveAvgPool3d(1))
+__global__ __launch_bounds__(256) void meanpool_bf16_kernel(const __bf16* __restrict__ x, int S, int Cp, int C,
+                                                            float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int s = slice; s < S; s += 4) acc += (float)x[((size_t)n * S + s) * Cp + c];
+    part[slice][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (slice == 0 && c < C)
+        out[(size_t)n * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)S;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline bool bf16_folded(const zsv_conv_desc* d) { return d->Cin <= 4; }
+static inline int bf16_cin_pitch(const zsv_conv_desc* d) { return bf16_folded(d) ? 4 : round_up(d->Cin, 32); }
+
+// row tile height: a function of Cout only, so that weights are packed once per layer
+static int bf16_bm(int M) {
+    if (M <= 64) return 64;
+    const int p128 = round_up(M, 128), p144 = round_up(M, 144);
+    return p144 < p128 ? 144 : 128;
+}
+
+static int bf16_check(const zsv_conv_desc* d) {
+    if (d == nullptr) return ZSV_E_NULL;
+    if (bf16_folded(d)) {
+        // the border is materialised in the input (pH = pW = 0) and may be wider than the taps need: a
+        // chunk reads 8 pixels starting at wo*sW, so Wi >= (Wo-1)*sW + 8 while Wo follows the true frame
+        if (d->pH != 0 || d->pW != 0 || d->kW > 8) return ZSV_E_UNSUPPORTED;
+        if (d->Wo <= 0 || d->sW <= 0 || (d->Wo - 1) * d->sW + 8 > d->Wi) return ZSV_E_BAD_SHAPE;
+        zsv_conv_desc tight = *d;
+        tight.Wi = (d->Wo - 1) * d->sW + d->kW;
+        const int st = conv_check(&tight);
+        if (st != ZSV_OK) return st;
+    } else {
+        const int st = conv_check(d);
+        if (st != ZSV_OK) return st;
+    }
+    const long in_elems = (long)d->N * d->Ti * d->Hi * d->Wi * bf16_cin_pitch(d);
+    const long out_vox = (long)d->N * d->To * d->Ho * d->Wo;
+    if (in_elems >= (1L << 31) || out_vox * round_up(d->Cout, 32) >= (1L << 31)) return ZSV_E_TOO_LARGE;
+    return ZSV_OK;
+}
+
+template <int TM, int TN, int WGM, int WGN>
+static void bf16_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp, const float* shift,
+                        const __bf16* r, __bf16* y) {
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    p.tiles_m = p.Mp / BM;
+    p.tiles_n = (p.P + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p, x, wp,
+                       shift, r, y);
+}
+
+}  // namespace zsv
+
+using namespace zsv;
+
+extern "C" {
+
+int32_t zsv_bf16_channel_pitch(int32_t channels) { return channels <= 4 ? 4 : round_up(channels, 32); }
+
+size_t zsv_conv3d_bf16_blob_bytes(const zsv_conv_desc* d) {
+    if (d == nullptr || bf16_check(d) != ZSV_OK) return 0;
+    const int bm = bf16_bm(d->Cout), Mp = round_up(d->Cout, bm);
+    const int taps = bf16_folded(d) ? d->kT * d->kH : d->kT * d->kH * d->kW;
+    const int nchunk = bf16_folded(d) ? 1 : round_up(d->Cin, 32) / 32;
+    return (size_t)taps * nchunk * Mp * 32 * 2 + (size_t)Mp * 4;
+}
+
+int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* scale, const float* shift, void* blob,
+                         void* stream) {
+    if (d == nullptr) return ZSV_E_NULL;
+    const int st = bf16_check(d);
+    if (st != ZSV_OK) return st;
+    if (w == nullptr || blob == nullptr) return ZSV_E_NULL;
+    const bool folded = bf16_folded(d);
+    const int bm = bf16_bm(d->Cout), Mp = round_up(d->Cout, bm);
+    const int taps = folded ? d->kT * d->kH : d->kT * d->kH * d->kW;
+    const int nchunk = folded ? 1 : round_up(d->Cin, 32) / 32;
+    const long total = (long)taps * nchunk * Mp * 32;
+    __bf16* wp = (__bf16*)blob;
+    float* shift_out = (float*)((char*)blob + total * 2);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale,
+                       shift, wp, shift_out, d->Cout, Mp, d->Cin, taps, nchunk, d->kW, folded ? 1 : 0, total);
+    return launch_status();
+}
+
+int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual, int fuse_relu,
+                        void* y, void* stream) {
+    if (d == nullptr) return ZSV_E_NULL;
+    const int st = bf16_check(d);
+    if (st != ZSV_OK) return st;
+    if (x == nullptr || blob == nullptr || y == nullptr) return ZSV_E_NULL;
+    const bool folded = bf16_folded(d);
+    Bf16Params p;
+    const int bm = bf16_bm(d->Cout);
+    p.M = d->Cout;
+    p.Mp = round_up(d->Cout, bm);
+    p.CoutP = round_up(d->Cout, 32);
+    const int cp = bf16_cin_pitch(d);
+    p.nchunk = folded ? 1 : cp / 32;
+    p.kT = d->kT; p.kH = d->kH; p.kW = folded ? 1 : d->kW;
+    p.nq = p.kT * p.kH * p.kW * p.nchunk;
+    p.sW = cp; p.sH = d->Wi * cp; p.sT = d->Hi * d->Wi * cp;
+    p.sN = (long)d->Ti * d->Hi * d->Wi * cp;
+    p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi;
+    p.Wo = d->Wo; p.HoWo = d->Ho * d->Wo; p.ToHoWo = d->To * d->Ho * d->Wo;
+    p.strT = d->sT; p.strH = d->sH; p.strW = d->sW;
+    p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
+    p.P = d->N * p.ToHoWo;
+    p.relu = fuse_relu ? 1 : 0;
+    const __bf16* wp = (const __bf16*)blob;
+    const float* shift = (const float*)((const char*)blob + (size_t)p.nq * p.Mp * 32 * 2);
+    const __bf16* xb = (const __bf16*)x;
+    const __bf16* rb = (const __bf16*)residual;
+    __bf16* yb = (__bf16*)y;
+    hipStream_t s = (hipStream_t)stream;
+    if (bm == 64) bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    else if (bm == 144) bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    else if ((long)(p.Mp / 128) * ((p.P + 255) / 256) < 384) bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);
+    else bf16_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    return launch_status();
+}
+
+int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, int32_t padH, int32_t padW,
+                     int32_t Hp, int32_t Wp, void* out, void* stream) {
+    if (N <= 0 || C <= 0 || C > 4 || T <= 0 || H <= 0 || W <= 0 || padH < 0 || padW < 0 || Hp < H + padH || Wp < W + padW)
+        return ZSV_E_BAD_SHAPE;
+    if (x == nullptr || out == nullptr) return ZSV_E_NULL;
+    const long total = (long)N * T * Hp * Wp;
+    if (total * 4 >= (1L << 31)) return ZSV_E_TOO_LARGE;
+    hipLaunchKernelGGL(clip_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, C, T,
+                       H, W, padH, padW, Hp, Wp, total, (__bf16*)out);
+    return launch_status();
+}
+
+int zsv_meanpool_bf16(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream) {
+    if (N <= 0 || S <= 0 || C <= 4) return ZSV_E_BAD_SHAPE;
+    if (x == nullptr || out == nullptr) return ZSV_E_NULL;
+    hipLaunchKernelGGL(meanpool_bf16_kernel, dim3((C + 63) / 64, N), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, S,
+                       round_up(C, 32), C, out);
+    return launch_status();
+}
+
+}  // extern "C"

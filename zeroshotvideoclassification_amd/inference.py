@@ -1,0 +1,240 @@
+"""bf16 evaluation engine: the reference's eval loop body (main.py:224-252, BASELINE config 5)
+with the VideoResNet trunk run in bf16 on ``zsv_conv3d_bf16_fwd``.
+
+``Bf16Engine(model)`` walks a ``network.Model`` whose trunk is a ``resnet.VideoResNet``
+(R(2+1)D-18 / R3D-18 / MC3-18), folds every eval-mode ``BatchNorm3d`` into the convolution in
+front of it (scale into the weights, shift into the epilogue -- resnet.py:40-52,94-98), fuses
+ReLU and the block's ``out += residual; relu`` (resnet.py:110-111) into the same epilogue, and
+packs the weights once.  Calling it has ``Model.forward``'s contract (network.py:533-600):
+``(bs, nc, 3, T, H, W) fp32 -> (emb (bs*nc, 300) fp32 unit-norm, None)``.  Activations are
+channels-last bf16 between layers; the 512-d pooled feature, the MLP head and the normalisation
+stay fp32 on the training path's kernels.
+
+The engine holds a snapshot of the weights: build it after loading / training, rebuild after the
+weights change.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from ctypes import byref
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import ConvDesc
+
+
+def _check_bf16(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: MI355X HIP tensor expected, got {t.device} (there is no CPU fallback)")
+    if t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise RuntimeError(f"{what}: contiguous bf16 tensor expected")
+
+
+def channel_pitch(channels: int) -> int:
+    return int(_lib.load().zsv_bf16_channel_pitch(int(channels)))
+
+
+def clip_to_bf16(x: torch.Tensor, pad_h: int, pad_w: int, hp: int, wp: int) -> torch.Tensor:
+    """(N, 3, T, H, W) fp32 -> [N][T][hp][wp][4] bf16 with the frame at (pad_h, pad_w) in a zero border."""
+    ops._require(x)
+    x = x.contiguous()
+    n, c, t, h, w = x.shape
+    out = torch.empty((n, t, hp, wp, 4), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().zsv_clip_to_bf16(x.data_ptr(), n, c, t, h, w, pad_h, pad_w, hp, wp, out.data_ptr(),
+                                            ops._stream()), "zsv_clip_to_bf16")
+    return out
+
+
+def pack_conv(d: ConvDesc, weight: torch.Tensor, scale: Optional[torch.Tensor], shift: Optional[torch.Tensor]) -> torch.Tensor:
+    """Packed bf16 weights (x scale per produced channel) + fp32 shifts for ``conv_bf16``."""
+    ops._require(weight, scale, shift)
+    lib = _lib.load()
+    nbytes = lib.zsv_conv3d_bf16_blob_bytes(byref(d))
+    if nbytes == 0:
+        raise RuntimeError("zsv_conv3d_bf16_blob_bytes: unsupported convolution geometry")
+    blob = torch.empty(int(nbytes), dtype=torch.uint8, device=weight.device)
+    _lib.check(lib.zsv_conv3d_bf16_pack(byref(d), weight.contiguous().data_ptr(), ops._ptr(scale), ops._ptr(shift),
+                                        blob.data_ptr(), ops._stream()), "zsv_conv3d_bf16_pack")
+    return blob
+
+
+def conv_bf16(d: ConvDesc, x: torch.Tensor, blob: torch.Tensor, residual: Optional[torch.Tensor] = None,
+              relu: bool = False) -> torch.Tensor:
+    """y[N][To][Ho][Wo][Cp] = relu?(conv(x) * scale + shift (+ residual)) in bf16."""
+    _check_bf16(x, "conv_bf16 input")
+    expect = (d.N, d.Ti, d.Hi, d.Wi, channel_pitch(d.Cin))
+    if tuple(x.shape) != expect:
+        raise RuntimeError(f"conv_bf16: input {tuple(x.shape)} does not match the descriptor {expect}")
+    y = torch.empty((d.N, d.To, d.Ho, d.Wo, channel_pitch(d.Cout)), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        _check_bf16(residual, "conv_bf16 residual")
+        if residual.shape != y.shape:
+            raise RuntimeError(f"conv_bf16: residual {tuple(residual.shape)} != output {tuple(y.shape)}")
+    _lib.check(_lib.load().zsv_conv3d_bf16_fwd(byref(d), x.data_ptr(), blob.data_ptr(), ops._ptr(residual),
+                                               1 if relu else 0, y.data_ptr(), ops._stream()), "zsv_conv3d_bf16_fwd")
+    return y
+
+
+def meanpool_bf16(x: torch.Tensor, channels: int) -> torch.Tensor:
+    """[N][T][H][W][Cp] bf16 -> (N, channels) fp32 mean over the voxels."""
+    _check_bf16(x, "meanpool_bf16 input")
+    n = x.shape[0]
+    s = x.shape[1] * x.shape[2] * x.shape[3]
+    out = torch.empty((n, channels), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().zsv_meanpool_bf16(x.data_ptr(), n, s, channels, out.data_ptr(), ops._stream()),
+               "zsv_meanpool_bf16")
+    return out
+
+
+def fold_bn(bn: Optional[nn.BatchNorm3d], conv: nn.Conv3d) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """(scale, shift) of ``bn.eval()(conv(x))``: gamma/sqrt(var+eps), beta - mean*scale (+ conv bias)."""
+    bias = conv.bias.detach().float() if conv.bias is not None else None
+    if bn is None:
+        return None, bias
+    inv = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+    gamma = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(inv)
+    beta = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(inv)
+    scale = gamma * inv
+    shift = beta - bn.running_mean.detach().double() * scale
+    if bias is not None:
+        shift = shift + bias.double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class _ConvOp:
+    """One folded convolution: geometry is resolved per input shape, the packed blob per layer."""
+
+    def __init__(self, conv: nn.Conv3d, bn: Optional[nn.BatchNorm3d], relu: bool):
+        self.weight = conv.weight.detach().float().contiguous()
+        self.scale, self.shift = fold_bn(bn, conv)
+        self.stride = tuple(conv.stride)
+        self.padding = tuple(conv.padding)
+        self.relu = relu
+        self.cout, self.cin = self.weight.shape[0], self.weight.shape[1]
+        self.kernel = tuple(self.weight.shape[2:])
+        if tuple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+            raise RuntimeError("Bf16Engine: dilation / groups are not used by the reference and not supported")
+        self.folded = self.cin <= 4            # the clip itself: border materialised, kw folded into K
+        self._blob = None
+
+    def input_border(self, h: int, w: int) -> Tuple[int, int, int, int]:
+        """(pad_h, pad_w, Hp, Wp) of the materialised border for the clip convolution."""
+        kt, kh, kw = self.kernel
+        ph, pw = self.padding[1], self.padding[2]
+        wo = (w + 2 * pw - kw) // self.stride[2] + 1
+        return ph, pw, h + 2 * ph, max(w + 2 * pw, (wo - 1) * self.stride[2] + 8)
+
+    def desc(self, n: int, t: int, h: int, w: int) -> ConvDesc:
+        """``h, w`` are the stored extents (border included for the clip convolution)."""
+        kt, kh, kw = self.kernel
+        pt, ph, pw = self.padding
+        if self.folded:
+            ph = pw = 0
+        st, sh, sw = self.stride
+        to = (t + 2 * pt - kt) // st + 1
+        ho = (h + 2 * ph - kh) // sh + 1
+        wo = (w + 2 * pw - kw) // sw + 1
+        return ConvDesc(n, self.cin, t, h, w, self.cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, wo: Optional[int] = None) -> torch.Tensor:
+        n, t, h, w, _ = x.shape
+        d = self.desc(n, t, h, w)
+        if wo is not None:
+            d.Wo = wo
+        if self._blob is None:
+            self._blob = pack_conv(d, self.weight, self.scale, self.shift)
+        return conv_bf16(d, x, self._blob, residual, self.relu)
+
+
+def _conv_bn_relu_chain(mods: List[nn.Module]) -> List[_ConvOp]:
+    """[Conv3d, BN?, ReLU?, Conv3d, ...] (nested Sequentials flattened) -> folded ops."""
+    flat: List[nn.Module] = []
+
+    def walk(m):
+        if isinstance(m, nn.Conv3d) or not isinstance(m, nn.Sequential):
+            flat.append(m)
+        else:
+            for c in m:
+                walk(c)
+    for m in mods:
+        walk(m)
+    out: List[_ConvOp] = []
+    i = 0
+    while i < len(flat):
+        conv = flat[i]
+        if not isinstance(conv, nn.Conv3d):
+            raise RuntimeError(f"Bf16Engine: expected a Conv3d, found {type(conv).__name__}")
+        i += 1
+        bn = None
+        if i < len(flat) and isinstance(flat[i], nn.BatchNorm3d):
+            bn = flat[i]
+            i += 1
+        relu = False
+        if i < len(flat) and isinstance(flat[i], nn.ReLU):
+            relu = True
+            i += 1
+        out.append(_ConvOp(conv, bn, relu))
+    return out
+
+
+class Bf16Engine:
+    """Eval-mode ``Model.forward`` (network.py:533-600) in bf16.  See the module docstring."""
+
+    def __init__(self, model: nn.Module):
+        from . import network, resnet
+        model = getattr(model, "module", model)
+        if not isinstance(model, network.Model) or not isinstance(model.model, resnet.VideoResNet):
+            raise RuntimeError("Bf16Engine supports network.Model over a resnet.VideoResNet trunk")
+        if next(model.parameters()).device.type != "cuda":
+            raise RuntimeError("Bf16Engine: the model must live on the MI355X HIP device (there is no CPU fallback)")
+        self.model = model
+        trunk = model.model
+        self.stem = _conv_bn_relu_chain(list(trunk.stem))
+        if not self.stem[0].folded:
+            raise RuntimeError("Bf16Engine: the stem's first convolution must take the clip (<= 4 channels)")
+        self.blocks = []
+        for layer in (trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4):
+            for block in layer:
+                if not isinstance(block, resnet.BasicBlock):
+                    raise RuntimeError("Bf16Engine: only BasicBlock trunks (the reference's *_18 models) are supported")
+                conv1 = _conv_bn_relu_chain(list(block.conv1))
+                conv2 = _conv_bn_relu_chain(list(block.conv2))
+                conv2[-1].relu = True                   # out += residual; relu (resnet.py:110-111)
+                down = _conv_bn_relu_chain(list(block.downsample)) if block.downsample is not None else None
+                self.blocks.append((conv1, conv2, down))
+        self.features = self.blocks[-1][1][-1].cout
+
+    @torch.no_grad()
+    def trunk(self, clips: torch.Tensor) -> torch.Tensor:
+        """(N, 3, T, H, W) fp32 -> pooled (N, 512) fp32 (VideoResNet.forward's first output)."""
+        first = self.stem[0]
+        n, _, t, h, w = clips.shape
+        pad_h, pad_w, hp, wp = first.input_border(h, w)
+        wo = (w + 2 * pad_w - first.kernel[2]) // first.stride[2] + 1
+        x = clip_to_bf16(clips, pad_h, pad_w, hp, wp)
+        x = first(x, wo=wo)
+        for op in self.stem[1:]:
+            x = op(x)
+        for conv1, conv2, down in self.blocks:
+            residual = x
+            if down is not None:
+                for op in down:
+                    residual = op(residual)
+            y = x
+            for op in conv1:
+                y = op(y)
+            for op in conv2[:-1]:
+                y = op(y)
+            x = conv2[-1](y, residual=residual)
+        return meanpool_bf16(x, self.features)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        bs, nc = x.shape[:2]
+        clips = x.reshape(bs * nc, *x.shape[2:])                    # network.py:534-535
+        pooled = self.trunk(clips)
+        emb = self.model.output2emb_proj(pooled)                       # network.py:595 (mean already taken)
+        return F.normalize(emb, dim=-1), None                          # network.py:596,600
