@@ -21,6 +21,8 @@
 // back as ds_read_b128 fragments.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
@@ -51,91 +53,137 @@ struct Bf16Params {
 // 16-byte slot swizzle of a 64-byte LDS row: ds_read_b128 serves lanes in the groups
 // {0-3,12-15,20-27},{4-11,16-19,28-31},... (MI355X_MICROARCH.md, LDS table); with slot ^= swz(row) the
 // 16 lanes of every group fall on 16 distinct slots of the 256-byte bank row.
-__device__ __forceinline__ int swz(int row) {
+__host__ __device__ __forceinline__ int swz(int row) {
     const int j = (row >> 2) & 3, g = j ^ (j >> 1);
     return ((g & 1) << 1) | (g >> 1);
 }
 
+// Channel (relative to the row tile) that packed row `rho` of a BM-row tile holds.  Row-block pairs
+// are interleaved so that in the epilogue a lane's 4 + 4 accumulator rows of blocks (2k, 2k+1) are 8
+// consecutive channels = one 16-byte store; an unpaired last block keeps the natural order.
+__host__ __device__ __forceinline__ int tile_channel(int rho, int bm) {
+    const int i = rho >> 4, r = rho & 15, blocks = bm >> 4;
+    if (i < (blocks & ~1)) return 32 * (i >> 1) + 8 * (r >> 2) + 4 * (i & 1) + (r & 3);
+    return rho;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// Fragment reads and their waits are written as asm: with an LDS-DMA in flight hipcc only ever emits
+// `s_waitcnt lgkmcnt(0)`, which would expose the latency of the newest ds_read at every use; here the
+// waits are counted (reads return in issue order) and tied to the registers they release.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8& a) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(N));
+}
+
+__device__ __forceinline__ void add_bf16x8(f32x4& lo, f32x4& hi, u32x4 r) {
+    lo[0] += __builtin_bit_cast(float, r[0] << 16); lo[1] += __builtin_bit_cast(float, r[0] & 0xffff0000u);
+    lo[2] += __builtin_bit_cast(float, r[1] << 16); lo[3] += __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    hi[0] += __builtin_bit_cast(float, r[2] << 16); hi[1] += __builtin_bit_cast(float, r[2] & 0xffff0000u);
+    hi[2] += __builtin_bit_cast(float, r[3] << 16); hi[3] += __builtin_bit_cast(float, r[3] & 0xffff0000u);
+}
+
+// Pipeline: a ring of 3 LDS stages filled by LDS-DMA (global_load_lds_dwordx4, no staging registers)
+// two K chunks ahead of the MFMAs; a stage is 1-KiB pieces (16 rows x 64 B) dealt round-robin to the 4
+// waves, each lane fetching the 16 bytes that belong at its (row, swizzled slot).  Every wave issues
+// the same number of DMAs per stage (NPW), so `s_waitcnt vmcnt(NPW)` retires exactly the older stage.
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const __bf16* __restrict__ X,
                                                            const __bf16* __restrict__ Wp,
                                                            const float* __restrict__ shift,
                                                            const __bf16* __restrict__ R, __bf16* __restrict__ Y) {
+#if defined(__HIP_DEVICE_COMPILE__)     // (address_space(3) casts: the host pass would drop the stub)
     static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGM == 1 || (TM % 2) == 0, "row-block pairs must not straddle waves");
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
-    constexpr int A_PIECES = BM * 4;                 // 16-byte pieces of one A stage
-    constexpr int NA = (A_PIECES + 255) / 256;
-    constexpr int NB = BN / 64;                      // voxel rows per thread
+    constexpr int NA_P = BM / 16, NB_P = BN / 16;    // 1-KiB pieces per stage
+    static_assert(NA_P >= 4 && NB_P % 4 == 0, "piece distribution");
+    constexpr int NAW = (NA_P + 3) / 4, NBW = NB_P / 4;
+    constexpr int NPW = NAW + NBW;                   // DMAs per wave per stage
     constexpr int STAGE = (BM + BN) * 64;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    constexpr int SHIFT_AT = 3 * STAGE;              // 1 KiB: this row tile's fp32 shifts
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WGM, wn = wave / WGM;
     const int tile = xcd_tile(gridDim.x, blockIdx.x);
     const int tm = tile % prm.tiles_m, tn = tile / prm.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- per-thread staging assignment -------------------------------------------------------
-    const int piece = tid & 3;
-    int b_base[NB], b_t0[NB], b_h0[NB], b_w0[NB], b_lds[NB];
+    // ---- DMA assignment ------------------------------------------------------------------------
+    // lane l of a piece fills row l/4, slot l%4 of the LDS image <- source slot (l%4) ^ swz(row)
+    const int srcslot = ((lane & 3) ^ swz(lane >> 2)) * 8;
+    int a_off[NAW], a_dst[NAW];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int r = (tid >> 2) + 64 * j;
-        const int p = n0 + r;
-        const bool pv = p < prm.P;
-        const int pp = pv ? p : 0;
-        const int n = pp / prm.ToHoWo;
-        int rem = pp - n * prm.ToHoWo;
-        const int to = rem / prm.HoWo;
-        rem -= to * prm.HoWo;
-        const int ho = rem / prm.Wo, wo = rem - ho * prm.Wo;
-        b_t0[j] = pv ? to * prm.strT - prm.pT : -0x100000;      // invalid voxel: every tap is out of range
-        b_h0[j] = ho * prm.strH - prm.pH;
-        b_w0[j] = wo * prm.strW - prm.pW;
-        b_base[j] = (int)(n * prm.sN) + b_t0[j] * prm.sT + b_h0[j] * prm.sH + b_w0[j] * prm.sW + piece * 8;
-        b_lds[j] = BM * 64 + r * 64 + ((piece ^ swz(r)) << 4);
+    for (int k = 0; k < NAW; ++k) {
+        int pa = wave + 4 * k;
+        if (pa >= NA_P) pa -= 4;                      // surplus slot: repeat this wave's previous piece
+        a_off[k] = (pa * 16 + (lane >> 2)) * 32 + srcslot;
+        a_dst[k] = pa * 1024;
     }
-    int a_src[NA], a_lds[NA];
+    int b_base[NBW], b_dst[NBW];
+    unsigned b_mask[NBW];                            // bit tap = the tap lies inside the input
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        int p = tid + 256 * j;
-        p = p < A_PIECES ? p : A_PIECES - 1;             // surplus threads repeat the last piece
-        a_src[j] = p * 8;
-        a_lds[j] = (p >> 2) * 64 + (((p & 3) ^ swz(p >> 2)) << 4);
+    for (int k = 0; k < NBW; ++k) {
+        const int pb = wave + 4 * k;
+        const int p = n0 + pb * 16 + (lane >> 2);
+        b_dst[k] = BM * 64 + pb * 1024;
+        b_mask[k] = 0;
+        b_base[k] = 0;
+        if (p < prm.P) {
+            const int n = p / prm.ToHoWo;
+            int rem = p - n * prm.ToHoWo;
+            const int to = rem / prm.HoWo;
+            rem -= to * prm.HoWo;
+            const int ho = rem / prm.Wo, wo = rem - ho * prm.Wo;
+            const int t0 = to * prm.strT - prm.pT, h0 = ho * prm.strH - prm.pH, w0 = wo * prm.strW - prm.pW;
+            b_base[k] = (int)(n * prm.sN) + t0 * prm.sT + h0 * prm.sH + w0 * prm.sW + srcslot;
+            unsigned m = 0;
+            int tap = 0;
+            for (int a = 0; a < prm.kT; ++a)
+                for (int b = 0; b < prm.kH; ++b)
+                    for (int c = 0; c < prm.kW; ++c, ++tap)
+                        m |= (unsigned)((unsigned)(t0 + a) < (unsigned)prm.Ti && (unsigned)(h0 + b) < (unsigned)prm.Hi &&
+                                        (unsigned)(w0 + c) < (unsigned)prm.Wi) << tap;
+            b_mask[k] = m;
+        }
     }
-    const __bf16* wq = Wp + (size_t)m0 * 32;             // chunk q lives at + q*Mp*32
+    const __bf16* wq = Wp + (size_t)m0 * 32;         // chunk q lives at + q*Mp*32
     const size_t wq_step = (size_t)prm.Mp * 32;
     const __bf16* zero = (const __bf16*)zsv_zero_line;
 
     // uniform walk over (tap, chunk)
-    int kt = 0, kh = 0, kw = 0, cc = 0;
-    u32x4 areg[NA], breg[NB];
-    auto load_stage = [&]() {
+    int kt = 0, kh = 0, kw = 0, cc = 0, tap_i = 0;
+    auto issue = [&](int buf) {
+        unsigned char* base = lds + buf * STAGE;
         const int tapoff = kt * prm.sT + kh * prm.sH + kw * prm.sW + cc * 32;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) areg[j] = *(const u32x4*)(wq + a_src[j]);
+        for (int k = 0; k < NAW; ++k)
+            __builtin_amdgcn_global_load_lds(wq + a_off[k], (lds_ptr_t)(base + a_dst[k]), 16, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const bool ok = (unsigned)(b_t0[j] + kt) < (unsigned)prm.Ti && (unsigned)(b_h0[j] + kh) < (unsigned)prm.Hi &&
-                            (unsigned)(b_w0[j] + kw) < (unsigned)prm.Wi;
-            const __bf16* src = ok ? X + (b_base[j] + tapoff) : zero;
-            breg[j] = *(const u32x4*)src;
+        for (int k = 0; k < NBW; ++k) {
+            const __bf16* src = ((b_mask[k] >> tap_i) & 1u) ? X + (b_base[k] + tapoff) : zero;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(base + b_dst[k]), 16, 0, 0);
         }
         wq += wq_step;
         if (++cc == prm.nchunk) {
             cc = 0;
+            ++tap_i;
             if (++kw == prm.kW) {
                 kw = 0;
                 if (++kh == prm.kH) { kh = 0; ++kt; }
             }
         }
-    };
-    auto write_stage = [&](int buf) {
-        unsigned char* base = lds + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) *(u32x4*)(base + a_lds[j]) = areg[j];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) *(u32x4*)(base + b_lds[j]) = breg[j];
     };
 
     f32x4 acc[TM][TN];
@@ -144,55 +192,119 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
     const int a_frag = wm * TM * 16 * 64 + frag_off;
     const int b_frag = BM * 64 + wn * TN * 16 * 64 + frag_off;
 
-    load_stage();
-    write_stage(0);
-    __syncthreads();
+    if (wave == 0) {                                  // oldest DMA of wave 0: retired by its first counted wait
+        const int l4 = lane < BM / 4 ? lane : BM / 4 - 1;
+        __builtin_amdgcn_global_load_lds(shift + m0 + 4 * l4, (lds_ptr_t)(lds + SHIFT_AT), 16, 0, 0);
+    }
+    issue(0);
+    if (prm.nq > 1) {
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt2 = 2;
     for (int q = 0; q < prm.nq; ++q) {
-        const bool more = q + 1 < prm.nq;
-        if (more) load_stage();
-        const unsigned char* s = lds + (q & 1) * STAGE;
-        bf16x8 bf[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *(const bf16x8*)(s + b_frag + j * 1024);
+        const bool ahead = q + 2 < prm.nq;
+        if (ahead) issue(nxt2);
+        // fragments: B0..B3, A0, A1 up front, then A(i+2) under the MFMAs of A(i); reads return in
+        // order, so before using A(i) at most min(2, TM-1-i) younger reads may still be out
+        static_assert(TN == 4, "fragment schedule is written for 4 column blocks");
+        const unsigned sa = lds_base + cur * STAGE + a_frag, sb = lds_base + cur * STAGE + b_frag;
+        bf16x8 bf[TN], af[3];
+        lds_read128<0>(bf[0], sb);
+        lds_read128<1024>(bf[1], sb);
+        lds_read128<2048>(bf[2], sb);
+        lds_read128<3072>(bf[3], sb);
+        lds_read128<0>(af[0], sa);
+        if (TM > 1) lds_read128<1024>(af[1], sa);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const bf16x8 af = *(const bf16x8*)(s + a_frag + i * 1024);
+            if (i + 2 < TM) lds_read128<0>(af[(i + 2) % 3], sa + (i + 2) * 1024);
+            if (i == 0) {
+                if (TM > 2) lds_wait<2>(af[0], bf[0], bf[1], bf[2], bf[3]);
+                else if (TM > 1) lds_wait<1>(af[0], bf[0], bf[1], bf[2], bf[3]);
+                else lds_wait<0>(af[0], bf[0], bf[1], bf[2], bf[3]);
+            } else if (i + 2 < TM) lds_wait<2>(af[i % 3]);
+            else if (i + 1 < TM) lds_wait<1>(af[i % 3]);
+            else lds_wait<0>(af[i % 3]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % 3], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) write_stage((q + 1) & 1);
-        __syncthreads();
+        // stage q+1 must have landed (all but this wave's newest NPW DMAs), for every wave
+        if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
 
-    // ---- epilogue: + shift (+ residual), relu, bf16, channels-last store ----------------------
-    // lane holds, per accumulator tile, 4 consecutive channels of one voxel = one 8-byte store
-    const int ch_lane = m0 + wm * TM * 16 + 4 * (lane >> 4);
+    // ---- epilogue: + shift (+ residual), relu, bf16, channels-last 16-byte stores ---------------
+    const float floor_ = prm.relu ? 0.f : -__builtin_inff();
+    const int g = lane >> 4;
+    const int ch_t = wm * TM * 16;                   // this wave's first channel inside the row tile
+    constexpr int NPAIR = TM / 2;
+    const float* sh = (const float*)(lds + SHIFT_AT);
+    auto finish = [&](auto has_res) {
+        constexpr bool HAS_RES = decltype(has_res)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
-        if (col >= prm.P) continue;
-        const size_t row_off = (size_t)col * prm.CoutP;
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+            const bool cv = col < prm.P;
+            const size_t row_off = (size_t)(cv ? col : 0) * prm.CoutP + m0;
+            u32x4 res[NPAIR > 0 ? NPAIR : 1];
+            u32x2 res_odd = u32x2{0u, 0u};
+            if (HAS_RES) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ch = ch_lane + i * 16;
-            if (ch >= prm.CoutP) continue;
-            f32x4 v = acc[i][j] + *(const f32x4*)(shift + ch);
-            if (R != nullptr) {
-                const bf16x4 r = *(const bf16x4*)(R + row_off + ch);
-                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+                for (int k = 0; k < NPAIR; ++k) {
+                    const int ch = ch_t + 32 * k + 8 * g;
+                    res[k] = *(const u32x4*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
+                }
+                if (TM & 1) {
+                    const int ch = ch_t + 16 * (TM - 1) + 4 * g;
+                    res_odd = *(const u32x2*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
+                }
             }
-            if (prm.relu) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+#pragma unroll
+            for (int k = 0; k < NPAIR; ++k) {
+                const int ch = ch_t + 32 * k + 8 * g;
+                f32x4 lo = acc[2 * k][j] + *(const f32x4*)(sh + ch);
+                f32x4 hi = acc[2 * k + 1][j] + *(const f32x4*)(sh + ch + 4);
+                if (HAS_RES) add_bf16x8(lo, hi, res[k]);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)fmaxf(lo[e], floor_);
+                    o[4 + e] = (__bf16)fmaxf(hi[e], floor_);
+                }
+                if (cv && m0 + ch < prm.CoutP) *(bf16x8*)(Y + row_off + ch) = o;
             }
-            bf16x4 o;
-            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-            *(bf16x4*)(Y + row_off + ch) = o;
+            if (TM & 1) {                             // unpaired last row block: 4 channels per lane
+                const int ch = ch_t + 16 * (TM - 1) + 4 * g;
+                f32x4 v = acc[TM - 1][j] + *(const f32x4*)(sh + ch);
+                if (HAS_RES) {
+                    v[0] += __builtin_bit_cast(float, res_odd[0] << 16);
+                    v[1] += __builtin_bit_cast(float, res_odd[0] & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, res_odd[1] << 16);
+                    v[3] += __builtin_bit_cast(float, res_odd[1] & 0xffff0000u);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(v[e], floor_);
+                if (cv && m0 + ch < prm.CoutP) *(bf16x4*)(Y + row_off + ch) = o;
+            }
         }
-    }
+    };
+    if (R != nullptr) finish(std::true_type{});
+    else finish(std::false_type{});
     // channels between the last packed row and the pitch (e.g. 144 -> 160) stay zero
     const int covered = prm.tiles_m * BM;
     if (tm == prm.tiles_m - 1 && covered < prm.CoutP) {
@@ -203,18 +315,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
             if (col < prm.P) *(u32x2*)(Y + (size_t)col * prm.CoutP + covered + 4 * k) = u32x2{0u, 0u};
         }
     }
+#endif
 }
 
 // Wp[q][Mp][32] <- w[Cout][Cin][kT][kH][kW] * scale[cout]; then Mp fp32 shifts.
 __global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                  const float* __restrict__ shift, __bf16* __restrict__ wp, float* __restrict__ shift_out,
-                                 int M, int Mp, int Cin, int taps, int nchunk, int kW, int folded, long total) {
+                                 int M, int Mp, int bm, int Cin, int taps, int nchunk, int kW, int folded, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < Mp) shift_out[idx] = (idx < M && shift != nullptr) ? shift[idx] : 0.f;
+    if (idx < Mp) shift_out[idx] = (idx < M && shift != nullptr) ? shift[idx] : 0.f;     // channel order
     if (idx >= total) return;
     const int k = (int)(idx & 31);
     const long rq = idx >> 5;
-    const int row = (int)(rq % Mp);
+    const int prow = (int)(rq % Mp);               // packed row -> the channel it holds
+    const int row = prow / bm * bm + tile_channel(prow % bm, bm);
     const int q = (int)(rq / Mp);
     float v = 0.f;
     if (row < M) {
@@ -295,6 +409,7 @@ static int bf16_check(const zsv_conv_desc* d) {
         const int st = conv_check(d);
         if (st != ZSV_OK) return st;
     }
+    if ((bf16_folded(d) ? d->kT * d->kH : d->kT * d->kH * d->kW) > 32) return ZSV_E_UNSUPPORTED;   // tap validity mask
     const long in_elems = (long)d->N * d->Ti * d->Hi * d->Wi * bf16_cin_pitch(d);
     const long out_vox = (long)d->N * d->To * d->Ho * d->Wo;
     if (in_elems >= (1L << 31) || out_vox * round_up(d->Cout, 32) >= (1L << 31)) return ZSV_E_TOO_LARGE;
@@ -302,13 +417,18 @@ static int bf16_check(const zsv_conv_desc* d) {
 }
 
 template <int TM, int TN, int WGM, int WGN>
-static void bf16_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp, const float* shift,
-                        const __bf16* r, __bf16* y) {
+static int bf16_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp, const float* shift,
+                       const __bf16* r, __bf16* y) {
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int LDS_BYTES = 3 * (BM + BN) * 64 + 1024;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, WGM, WGN>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
     p.tiles_m = p.Mp / BM;
     p.tiles_n = (p.P + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p, x, wp,
-                       shift, r, y);
+    hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, stream, p, x,
+                       wp, shift, r, y);
+    return launch_status();
 }
 
 }  // namespace zsv
@@ -341,7 +461,7 @@ int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* sc
     __bf16* wp = (__bf16*)blob;
     float* shift_out = (float*)((char*)blob + total * 2);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, scale,
-                       shift, wp, shift_out, d->Cout, Mp, d->Cin, taps, nchunk, d->kW, folded ? 1 : 0, total);
+                       shift, wp, shift_out, d->Cout, Mp, bm, d->Cin, taps, nchunk, d->kW, folded ? 1 : 0, total);
     return launch_status();
 }
 
@@ -375,11 +495,10 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     const __bf16* rb = (const __bf16*)residual;
     __bf16* yb = (__bf16*)y;
     hipStream_t s = (hipStream_t)stream;
-    if (bm == 64) bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
-    else if (bm == 144) bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
-    else if ((long)(p.Mp / 128) * ((p.P + 255) / 256) < 384) bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);
-    else bf16_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
-    return launch_status();
+    if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    if (bm == 144) return bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    if ((long)(p.Mp / 128) * ((p.P + 255) / 256) < 384) return bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);
+    return bf16_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
 }
 
 int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, int32_t padH, int32_t padW,
