@@ -21,6 +21,8 @@
 // back as ds_read_b128 fragments.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "conv_params.h"
@@ -51,12 +53,11 @@ struct Bf16Params {
 };
 
 // 16-byte slot swizzle of a 64-byte LDS row: ds_read_b128 serves lanes in the groups
-// {0-3,12-15,20-27},{4-11,16-19,28-31},... (MI355X_MICROARCH.md, LDS table); with slot ^= swz(row) the
-// 16 lanes of every group fall on 16 distinct slots of the 256-byte bank row.
-__host__ __device__ __forceinline__ int swz(int row) {
-    const int j = (row >> 2) & 3, g = j ^ (j >> 1);
-    return ((g & 1) << 1) | (g >> 1);
-}
+// {0-3,12-15,20-27},{4-11,16-19,28-31},... (MI355X_MICROARCH.md, LDS table).  With slot ^= swz(row)
+// the 16 lanes of every group fall on 16 distinct slots of the 256-byte bank row, for a fragment of 16
+// consecutive rows starting at ANY row (checked exhaustively) -- the shifted reads of
+// conv_bf16_same_kernel need that.
+__host__ __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 // Channel (relative to the row tile) that packed row `rho` of a BM-row tile holds.  Row-block pairs
 // are interleaved so that in the epilogue a lane's 4 + 4 accumulator rows of blocks (2k, 2k+1) are 8
@@ -90,6 +91,119 @@ __device__ __forceinline__ void add_bf16x8(f32x4& lo, f32x4& hi, u32x4 r) {
     lo[2] += __builtin_bit_cast(float, r[1] << 16); lo[3] += __builtin_bit_cast(float, r[1] & 0xffff0000u);
     hi[0] += __builtin_bit_cast(float, r[2] << 16); hi[1] += __builtin_bit_cast(float, r[2] & 0xffff0000u);
     hi[2] += __builtin_bit_cast(float, r[3] << 16); hi[3] += __builtin_bit_cast(float, r[3] & 0xffff0000u);
+}
+
+// One K chunk of a wave's tile: B0..B3, A0, A1 fragments up front, then A(i+2) under the MFMAs of
+// A(i); reads return in issue order, so before using A(i) at most min(2, TM-1-i) younger reads may
+// still be out.  MASKED: column block j is zeroed unless keep_j != 0 (a tap outside the input).
+template <int TM, int TN, bool MASKED>
+__device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, unsigned sb, unsigned keep0, unsigned keep1,
+                                          unsigned keep2, unsigned keep3) {
+    static_assert(TN == 4, "fragment schedule is written for 4 column blocks");
+    bf16x8 bf[TN], af[3];
+    lds_read128<0>(bf[0], sb);
+    lds_read128<1024>(bf[1], sb);
+    lds_read128<2048>(bf[2], sb);
+    lds_read128<3072>(bf[3], sb);
+    lds_read128<0>(af[0], sa);
+    if (TM > 1) lds_read128<1024>(af[1], sa);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        if (i + 2 < TM) lds_read128<0>(af[(i + 2) % 3], sa + (i + 2) * 1024);
+        if (i == 0) {
+            if (TM > 2) lds_wait<2>(af[0], bf[0], bf[1], bf[2], bf[3]);
+            else if (TM > 1) lds_wait<1>(af[0], bf[0], bf[1], bf[2], bf[3]);
+            else lds_wait<0>(af[0], bf[0], bf[1], bf[2], bf[3]);
+            if (MASKED) {
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                bf[0] = keep0 ? bf[0] : z;
+                bf[1] = keep1 ? bf[1] : z;
+                bf[2] = keep2 ? bf[2] : z;
+                bf[3] = keep3 ? bf[3] : z;
+            }
+        } else if (i + 2 < TM) lds_wait<2>(af[i % 3]);
+        else if (i + 1 < TM) lds_wait<1>(af[i % 3]);
+        else lds_wait<0>(af[i % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % 3], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// + shift (+ residual), relu, bf16, channels-last stores (16 bytes per lane for paired row blocks);
+// `sh` = this row tile's shifts in LDS.
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM][TN], const float* sh,
+                                         const __bf16* __restrict__ R, __bf16* __restrict__ Y, int m0, int n0, int tm,
+                                         int wm, int wn, int tid) {
+    const int lane = tid & 63;
+    const float floor_ = prm.relu ? 0.f : -__builtin_inff();
+    const int g = lane >> 4;
+    const int ch_t = wm * TM * 16;                   // this wave's first channel inside the row tile
+    constexpr int NPAIR = TM / 2;
+    auto finish = [&](auto has_res) {
+        constexpr bool HAS_RES = decltype(has_res)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+            const bool cv = col < prm.P;
+            const size_t row_off = (size_t)(cv ? col : 0) * prm.CoutP + m0;
+            u32x4 res[NPAIR > 0 ? NPAIR : 1];
+            u32x2 res_odd = u32x2{0u, 0u};
+            if (HAS_RES) {
+#pragma unroll
+                for (int k = 0; k < NPAIR; ++k) {
+                    const int ch = ch_t + 32 * k + 8 * g;
+                    res[k] = *(const u32x4*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
+                }
+                if (TM & 1) {
+                    const int ch = ch_t + 16 * (TM - 1) + 4 * g;
+                    res_odd = *(const u32x2*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NPAIR; ++k) {
+                const int ch = ch_t + 32 * k + 8 * g;
+                f32x4 lo = acc[2 * k][j] + *(const f32x4*)(sh + ch);
+                f32x4 hi = acc[2 * k + 1][j] + *(const f32x4*)(sh + ch + 4);
+                if (HAS_RES) add_bf16x8(lo, hi, res[k]);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (__bf16)fmaxf(lo[e], floor_);
+                    o[4 + e] = (__bf16)fmaxf(hi[e], floor_);
+                }
+                if (cv && m0 + ch < prm.CoutP) *(bf16x8*)(Y + row_off + ch) = o;
+            }
+            if (TM & 1) {                             // unpaired last row block: 4 channels per lane
+                const int ch = ch_t + 16 * (TM - 1) + 4 * g;
+                f32x4 v = acc[TM - 1][j] + *(const f32x4*)(sh + ch);
+                if (HAS_RES) {
+                    v[0] += __builtin_bit_cast(float, res_odd[0] << 16);
+                    v[1] += __builtin_bit_cast(float, res_odd[0] & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, res_odd[1] << 16);
+                    v[3] += __builtin_bit_cast(float, res_odd[1] & 0xffff0000u);
+                }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(v[e], floor_);
+                if (cv && m0 + ch < prm.CoutP) *(bf16x4*)(Y + row_off + ch) = o;
+            }
+        }
+    };
+    if (R != nullptr) finish(std::true_type{});
+    else finish(std::false_type{});
+    // channels between the last packed row and the pitch (e.g. 144 -> 160) stay zero
+    const int covered = prm.tiles_m * BM;
+    if (tm == prm.tiles_m - 1 && covered < prm.CoutP) {
+        const int per_col = (prm.CoutP - covered) >> 2;            // 8-byte pieces per voxel
+        for (int idx = tid; idx < BN * per_col; idx += 256) {
+            const int c = idx / per_col, k = idx - c * per_col;
+            const int col = n0 + c;
+            if (col < prm.P) *(u32x2*)(Y + (size_t)col * prm.CoutP + covered + 4 * k) = u32x2{0u, 0u};
+        }
+    }
 }
 
 // Pipeline: a ring of 3 LDS stages filled by LDS-DMA (global_load_lds_dwordx4, no staging registers)
@@ -213,32 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
     for (int q = 0; q < prm.nq; ++q) {
         const bool ahead = q + 2 < prm.nq;
         if (ahead) issue(nxt2);
-        // fragments: B0..B3, A0, A1 up front, then A(i+2) under the MFMAs of A(i); reads return in
-        // order, so before using A(i) at most min(2, TM-1-i) younger reads may still be out
-        static_assert(TN == 4, "fragment schedule is written for 4 column blocks");
-        const unsigned sa = lds_base + cur * STAGE + a_frag, sb = lds_base + cur * STAGE + b_frag;
-        bf16x8 bf[TN], af[3];
-        lds_read128<0>(bf[0], sb);
-        lds_read128<1024>(bf[1], sb);
-        lds_read128<2048>(bf[2], sb);
-        lds_read128<3072>(bf[3], sb);
-        lds_read128<0>(af[0], sa);
-        if (TM > 1) lds_read128<1024>(af[1], sa);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (i + 2 < TM) lds_read128<0>(af[(i + 2) % 3], sa + (i + 2) * 1024);
-            if (i == 0) {
-                if (TM > 2) lds_wait<2>(af[0], bf[0], bf[1], bf[2], bf[3]);
-                else if (TM > 1) lds_wait<1>(af[0], bf[0], bf[1], bf[2], bf[3]);
-                else lds_wait<0>(af[0], bf[0], bf[1], bf[2], bf[3]);
-            } else if (i + 2 < TM) lds_wait<2>(af[i % 3]);
-            else if (i + 1 < TM) lds_wait<1>(af[i % 3]);
-            else lds_wait<0>(af[i % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % 3], bf[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        mfma_step<TM, TN, false>(acc, lds_base + cur * STAGE + a_frag, lds_base + cur * STAGE + b_frag, 0u, 0u, 0u, 0u);
         // stage q+1 must have landed (all but this wave's newest NPW DMAs), for every wave
         if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -247,74 +336,171 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
         nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
 
-    // ---- epilogue: + shift (+ residual), relu, bf16, channels-last 16-byte stores ---------------
-    const float floor_ = prm.relu ? 0.f : -__builtin_inff();
-    const int g = lane >> 4;
-    const int ch_t = wm * TM * 16;                   // this wave's first channel inside the row tile
-    constexpr int NPAIR = TM / 2;
-    const float* sh = (const float*)(lds + SHIFT_AT);
-    auto finish = [&](auto has_res) {
-        constexpr bool HAS_RES = decltype(has_res)::value;
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
+#endif
+}
+
+// Stride-1 "same" convolutions with kW = 3 (the 1x3x3 spatial convs of Conv2Plus1D, resnet.py:40-45,
+// and 3x3x3, resnet.py:23-30): in the flattened voxel index v = ((n*T + t)*H + h)*W + w a tap is a
+// constant shift  d = (kt-pT)*H*W + (kh-pH)*W + (kw-pW)  plus a per-voxel border test.  For one
+// (kt, kh) the three kw taps read rows v+d, v+d+1, v+d+2: ONE LDS image of BN+2 consecutive input rows
+// serves all three (fragments are read at row offsets 0/1/2), and the border test becomes a per-lane
+// zeroing of the B fragment instead of a per-row address select.  That cuts the bytes gathered from
+// L2 into LDS -- the limiter of the per-tap kernel on these layers -- by 1.7x for Cin = 64.
+// LDS: ring of 3 A stages (per tap) + ring of 2 B images (per (kt,kh), chunk) + shifts.
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, const __bf16* __restrict__ X,
+                                                                const __bf16* __restrict__ Wp,
+                                                                const float* __restrict__ shift,
+                                                                const __bf16* __restrict__ R, __bf16* __restrict__ Y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGM == 1 || (TM % 2) == 0, "row-block pairs must not straddle waves");
+    constexpr int KW = 3;
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int NA_P = BM / 16, NI_P = (BN + KW - 1 + 15) / 16;     // 1-KiB pieces: A stage, B image
+    constexpr int NAW = (NA_P + 3) / 4, NIW = (NI_P + 3) / 4;
+    constexpr int A_STAGE = BM * 64, IMG = NI_P * 1024;
+    constexpr int IMG_AT = 3 * A_STAGE, SHIFT_AT = IMG_AT + 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int tm = tile % prm.tiles_m, tn = tile / prm.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int srcslot = ((lane & 3) ^ swz(lane >> 2)) * 8;
+    int a_off[NAW], a_dst[NAW];
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        int pa = wave + 4 * k;
+        if (pa >= NA_P) pa -= 4;
+        a_off[k] = (pa * 16 + (lane >> 2)) * 32 + srcslot;
+        a_dst[k] = pa * 1024;
+    }
+    int i_row[NIW], i_dst[NIW];                      // image row this lane fills, per piece
+#pragma unroll
+    for (int k = 0; k < NIW; ++k) {
+        int pi = wave + 4 * k;
+        if (pi >= NI_P) pi -= 4;
+        i_row[k] = n0 + pi * 16 + (lane >> 2);
+        i_dst[k] = pi * 1024;
+    }
+    // border masks of this lane's 4 columns: bit tap = the tap reads inside the input.  One decode,
+    // then +16 voxels per column block (carry into h, t).
+    unsigned mask[TN];
+    {
+        const int p0 = n0 + wn * TN * 16 + (lane & 15);
+        int rem = p0 % prm.ToHoWo;
+        int t = rem / prm.HoWo;
+        rem -= t * prm.HoWo;
+        int h = rem / prm.Wo, w = rem - h * prm.Wo;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
-            const bool cv = col < prm.P;
-            const size_t row_off = (size_t)(cv ? col : 0) * prm.CoutP + m0;
-            u32x4 res[NPAIR > 0 ? NPAIR : 1];
-            u32x2 res_odd = u32x2{0u, 0u};
-            if (HAS_RES) {
-#pragma unroll
-                for (int k = 0; k < NPAIR; ++k) {
-                    const int ch = ch_t + 32 * k + 8 * g;
-                    res[k] = *(const u32x4*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
-                }
-                if (TM & 1) {
-                    const int ch = ch_t + 16 * (TM - 1) + 4 * g;
-                    res_odd = *(const u32x2*)(R + row_off + (m0 + ch < prm.CoutP ? ch : 0));
-                }
+            unsigned m = 0;
+            if (p0 + 16 * j < prm.P) {
+                unsigned mt = 0, mh = 0, mw = 0;
+                for (int a = 0; a < prm.kT; ++a) mt |= (unsigned)((unsigned)(t + a - prm.pT) < (unsigned)prm.Ti) << a;
+                for (int b = 0; b < prm.kH; ++b) mh |= (unsigned)((unsigned)(h + b - prm.pH) < (unsigned)prm.Hi) << b;
+                for (int c = 0; c < KW; ++c) mw |= (unsigned)((unsigned)(w + c - prm.pW) < (unsigned)prm.Wi) << c;
+                int tap = 0;
+                for (int a = 0; a < prm.kT; ++a)
+                    for (int b = 0; b < prm.kH; ++b, tap += KW)
+                        if (((mt >> a) & (mh >> b)) & 1u) m |= mw << tap;
             }
-#pragma unroll
-            for (int k = 0; k < NPAIR; ++k) {
-                const int ch = ch_t + 32 * k + 8 * g;
-                f32x4 lo = acc[2 * k][j] + *(const f32x4*)(sh + ch);
-                f32x4 hi = acc[2 * k + 1][j] + *(const f32x4*)(sh + ch + 4);
-                if (HAS_RES) add_bf16x8(lo, hi, res[k]);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = (__bf16)fmaxf(lo[e], floor_);
-                    o[4 + e] = (__bf16)fmaxf(hi[e], floor_);
-                }
-                if (cv && m0 + ch < prm.CoutP) *(bf16x8*)(Y + row_off + ch) = o;
+            mask[j] = m;
+            w += 16;
+            while (w >= prm.Wo) {
+                w -= prm.Wo;
+                if (++h == prm.Hi) { h = 0; if (++t == prm.Ti) t = 0; }
             }
-            if (TM & 1) {                             // unpaired last row block: 4 channels per lane
-                const int ch = ch_t + 16 * (TM - 1) + 4 * g;
-                f32x4 v = acc[TM - 1][j] + *(const f32x4*)(sh + ch);
-                if (HAS_RES) {
-                    v[0] += __builtin_bit_cast(float, res_odd[0] << 16);
-                    v[1] += __builtin_bit_cast(float, res_odd[0] & 0xffff0000u);
-                    v[2] += __builtin_bit_cast(float, res_odd[1] << 16);
-                    v[3] += __builtin_bit_cast(float, res_odd[1] & 0xffff0000u);
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(v[e], floor_);
-                if (cv && m0 + ch < prm.CoutP) *(bf16x4*)(Y + row_off + ch) = o;
-            }
-        }
-    };
-    if (R != nullptr) finish(std::true_type{});
-    else finish(std::false_type{});
-    // channels between the last packed row and the pitch (e.g. 144 -> 160) stay zero
-    const int covered = prm.tiles_m * BM;
-    if (tm == prm.tiles_m - 1 && covered < prm.CoutP) {
-        const int per_col = (prm.CoutP - covered) >> 2;            // 8-byte pieces per voxel
-        for (int idx = tid; idx < BN * per_col; idx += 256) {
-            const int c = idx / per_col, k = idx - c * per_col;
-            const int col = n0 + c;
-            if (col < prm.P) *(u32x2*)(Y + (size_t)col * prm.CoutP + covered + 4 * k) = u32x2{0u, 0u};
         }
     }
+    const __bf16* zero = (const __bf16*)zsv_zero_line;
+    const size_t wq_step = (size_t)prm.Mp * 32;
+    const __bf16* w_tile = Wp + (size_t)m0 * 32;
+
+    // step = (group (kt,kh), chunk cc, kw); image = (group, cc)
+    const int nimg = prm.kT * prm.kH * prm.nchunk;
+    const int nsteps = nimg * KW;
+    int a_grp = 0, a_cc = 0, a_kw = 0;               // walk of the A issue
+    auto issue_a = [&](int buf) {
+        const __bf16* wq = w_tile + (size_t)((a_grp * KW + a_kw) * prm.nchunk + a_cc) * wq_step;
+        unsigned char* base = lds + buf * A_STAGE;
+#pragma unroll
+        for (int k = 0; k < NAW; ++k) __builtin_amdgcn_global_load_lds(wq + a_off[k], (lds_ptr_t)(base + a_dst[k]), 16, 0, 0);
+        if (++a_kw == KW) {
+            a_kw = 0;
+            if (++a_cc == prm.nchunk) { a_cc = 0; ++a_grp; }
+        }
+    };
+    int b_kt = 0, b_kh = 0, b_cc = 0;                // walk of the B image issue
+    auto issue_b = [&](int buf) {
+        const int shift_rows = (b_kt - prm.pT) * prm.HoWo + (b_kh - prm.pH) * prm.Wo - prm.pW;
+        unsigned char* base = lds + IMG_AT + buf * IMG;
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int src = i_row[k] + shift_rows;
+            const __bf16* ptr = (unsigned)src < (unsigned)prm.P ? X + ((size_t)src * prm.sW + b_cc * 32 + srcslot) : zero;
+            __builtin_amdgcn_global_load_lds(ptr, (lds_ptr_t)(base + i_dst[k]), 16, 0, 0);
+        }
+        if (++b_cc == prm.nchunk) {
+            b_cc = 0;
+            if (++b_kh == prm.kH) { b_kh = 0; ++b_kt; }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned a_frag = lds_base + wm * TM * 16 * 64 + (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    unsigned b_frag[KW];                             // fragment base per kw: rows (l&15) + kw of the column block
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+        const int x = (lane & 15) + c;
+        b_frag[c] = lds_base + IMG_AT + (wn * TN * 16 + x) * 64 + (((lane >> 4) ^ swz(x)) << 4);
+    }
+
+    if (wave == 0) {
+        const int l4 = lane < BM / 4 ? lane : BM / 4 - 1;
+        __builtin_amdgcn_global_load_lds(shift + m0 + 4 * l4, (lds_ptr_t)(lds + SHIFT_AT), 16, 0, 0);
+    }
+    issue_b(0);
+    issue_a(0);
+    issue_a(1);                                      // nsteps >= 3
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int abuf = 0, abuf2 = 2, tap = 0;
+    for (int img = 0; img < nimg; ++img) {
+        const unsigned img_off = (img & 1) * IMG;
+#pragma unroll
+        for (int c = 0; c < KW; ++c) {
+            const int step = img * KW + c;
+            const bool more_a = step + 2 < nsteps;
+            const bool more_b = c == 0 && img + 1 < nimg;
+            if (more_a) issue_a(abuf2);              // A first: the image issued after it may stay in flight
+            if (more_b) issue_b((img + 1) & 1);
+            const int tp = tap + c;
+            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag[c] + img_off, (mask[0] >> tp) & 1u,
+                                    (mask[1] >> tp) & 1u, (mask[2] >> tp) & 1u, (mask[3] >> tp) & 1u);
+            // A(step+1) -- and before an image's first step the image -- must have landed, for every wave
+            if (c < KW - 1 && more_a && img + 1 < nimg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW + NIW) : "memory");
+            else if (c == KW - 1 && more_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            abuf = abuf == 2 ? 0 : abuf + 1;
+            abuf2 = abuf2 == 2 ? 0 : abuf2 + 1;
+        }
+        tap += KW;
+        if (img % prm.nchunk != prm.nchunk - 1) tap -= KW;      // same (kt,kh) group, next chunk
+    }
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
 #endif
 }
 
@@ -431,6 +617,27 @@ static int bf16_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, const
     return launch_status();
 }
 
+template <int TM, int TN, int WGM, int WGN>
+static int bf16_same_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp, const float* shift,
+                            const __bf16* r, __bf16* y) {
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int LDS_BYTES = 3 * BM * 64 + 2 * ((BN + 2 + 15) / 16) * 1024 + 1024;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_bf16_same_kernel<TM, TN, WGM, WGN>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    p.tiles_m = p.Mp / BM;
+    p.tiles_n = (p.P + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_bf16_same_kernel<TM, TN, WGM, WGN>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, stream,
+                       p, x, wp, shift, r, y);
+    return launch_status();
+}
+
+// stride 1, output extents = input extents, kW = 3 with pW = 1: taps are flattened shifts
+static bool bf16_same_applicable(const zsv_conv_desc* d) {
+    return !bf16_folded(d) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->kW == 3 && d->pW == 1 && d->To == d->Ti &&
+           d->Ho == d->Hi && d->Wo == d->Wi && getenv("ZSV_BF16_NO_SAME") == nullptr;
+}
+
 }  // namespace zsv
 
 using namespace zsv;
@@ -495,9 +702,16 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     const __bf16* rb = (const __bf16*)residual;
     __bf16* yb = (__bf16*)y;
     hipStream_t s = (hipStream_t)stream;
+    const bool small = (long)(p.Mp / 128) * ((p.P + 255) / 256) < 384;      // too few 128x256 tiles to fill the chip
+    // (the 64-row wave tiles of the small-P configuration have too few MFMAs per step to hide the
+    // fragment masking of the shared-image kernel: measured slower there)
+    if (bf16_same_applicable(d) && bm != 64 && !(bm == 128 && small)) {
+        if (bm == 144) return bf16_same_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+        return bf16_same_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+    }
     if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 144) return bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
-    if ((long)(p.Mp / 128) * ((p.P + 255) / 256) < 384) return bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);
+    if (small) return bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);
     return bf16_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
 }
 
