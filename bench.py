@@ -97,7 +97,7 @@ def pmc_traffic(n_clips: int):
     path = os.path.join(ROOT, "profiles", "r01_s1_hbm_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]["conv_tap_dma_kernel<9, 2, 1, 4, 1>"]
+            k = json.load(f)["kernels"]["conv_tap_dma_kernel<9, 2, 1, 4, 1, 4, 9>"]
         return round(k["hbm_bytes"]) if n_clips == CLIPS_PER_GPU else None
     except Exception:
         return None
