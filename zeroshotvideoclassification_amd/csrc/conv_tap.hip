@@ -284,15 +284,18 @@ int splitk_reduce(const float* slabs, int ksplit, long elems, int M, int oS, con
 
 // ---------------------------------------------------------------------------------------------
 struct TapCfg { int bm, bn; };
-static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}};
+static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}, {64, 256}};
+static const int kNumTapCfgs = 6;
 
 static int tap_pick(const IgemmParams& prm) {
     // Cost model: whole rounds of the 1024 resident workgroups (256 CUs x 4) times the tile's MACs,
     // with a small penalty for the narrow row tiles (fewer MFMAs per fragment read).
-    static const double penalty[5] = {1.00, 1.00, 1.05, 1.08, 1.15};
+    static const double penalty[kNumTapCfgs] = {1.00, 1.00, 1.05, 1.08, 1.15, 0.97};
+    // (64x256: 64x64 wave tiles, half the fragment reads per MFMA of 64x128 -- +5 % on S1 dgrad / T1 forward
+    //  even at 3 waves/SIMD; a 144x256 tile drops to 1 wave/SIMD and loses 15 %)
     int best = 0;
     double best_w = 1e300;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < kNumTapCfgs; ++i) {
         const double tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
         const double tn = (double)(((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn);
         const double tiles = tm * tn;
@@ -307,9 +310,13 @@ static int tap_pick(const IgemmParams& prm) {
             w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i];
             if (tiles < 512.0) w *= (512.0 / tiles) > 4.0 ? 4.0 : (512.0 / tiles);
         }
+        // 64x256 only where one row tile covers the problem (M <= 64, the 1.1 M-voxel layer1 / stem
+        // launches): on wider outputs a sweep of all configurations found it better on some mid-size
+        // layers and worse on as many -- not worth a table
+        if (i == 5 && (prm.M > 64 || getenv("ZSV_NO_CFG5"))) continue;
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
-    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % 5;
+    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % kNumTapCfgs;
     return best;
 }
 
@@ -406,7 +413,8 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
         case 1: return tap_launch<4, 4, 2, 2>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
         case 2: return tap_launch<5, 2, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
         case 3: return tap_launch<4, 2, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
-        default: return tap_launch<3, 4, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        case 4: return tap_launch<3, 4, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
+        default: return tap_launch<4, 4, 1, 4>(prm, Wp, G, bias, C, tiles_m, Mp, nblk, stream);
     }
 }
 
