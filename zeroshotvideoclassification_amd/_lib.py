@@ -13,7 +13,7 @@ import threading
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzsv_hip.so")
+LIB_PATH = os.environ.get("ZSV_LIB_PATH") or os.path.join(_HERE, "libzsv_hip.so")   # (override: A/B of two builds)
 
 
 class ConvDesc(Structure):

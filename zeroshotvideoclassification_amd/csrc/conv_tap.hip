@@ -287,33 +287,48 @@ struct TapCfg { int bm, bn; };
 static const TapCfg kTapCfgs[] = {{144, 128}, {128, 128}, {80, 128}, {64, 128}, {48, 256}, {64, 256}};
 static const int kNumTapCfgs = 6;
 
+static long tap_ksplit_for(long tiles, long nchunks) {
+    // 1024 workgroups are resident at once (256 CUs x 4); split K when one round is under-filled
+    long thresh = 700, target = 1024;
+    if (getenv("ZSV_NO_SPLITK")) return 1;
+    if (const char* e = getenv("ZSV_SPLITK_THRESH")) thresh = atol(e);
+    if (tiles >= thresh || nchunks < 32) return 1;
+    long ks = (target + tiles / 2) / tiles;              // nearest whole multiple of the tile count
+    if (ks > nchunks / 12) ks = nchunks / 12;            // >= 12 chunks per part
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : ks;
+}
+
 static int tap_pick(const IgemmParams& prm) {
-    // Cost model: whole rounds of the 1024 resident workgroups (256 CUs x 4) times the tile's MACs,
-    // with a small penalty for the narrow row tiles (fewer MFMAs per fragment read).
-    static const double penalty[kNumTapCfgs] = {1.00, 1.00, 1.05, 1.08, 1.15, 0.97};
+    // Cost model, fitted on a sweep of every configuration over the R(2+1)D-18 layers at N = 22
+    // (tools/conv_bench.py with ZSV_CONV_CFG=0..5; within 0.5 % of the per-layer best overall):
+    // padded MACs x a per-shape efficiency factor x
+    //   - above one round of the 1024 resident workgroups: a partial last round costs ~30 % of what
+    //     whole-round accounting would charge (slots are refilled as they free up);
+    //   - below one round: (1024 / workgroups)^0.4 -- fewer co-resident workgroups each run faster,
+    //     so an under-filled chip loses less than proportionally, but more (smaller) tiles still win.
+    // Workgroups = tiles x the split-K factor the launch will use.
+    static const double penalty[kNumTapCfgs] = {1.00, 1.00, 1.02, 1.04, 1.15, 0.97};
     // (64x256: 64x64 wave tiles, half the fragment reads per MFMA of 64x128 -- +5 % on S1 dgrad / T1 forward
     //  even at 3 waves/SIMD; a 144x256 tile drops to 1 wave/SIMD and loses 15 %)
     int best = 0;
     double best_w = 1e300;
+    const long nchunks = (long)prm.taps * ((prm.gC + 15) / 16);
     for (int i = 0; i < kNumTapCfgs; ++i) {
-        const double tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
-        const double tn = (double)(((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn);
-        const double tiles = tm * tn;
-        double w;
-        if (tiles > 1024.0) {
-            // workgroups are re-dispatched as slots free up, so a partial last round costs about
-            // half of what whole-round accounting would charge
-            const double r = tiles / 1024.0, rc = (double)(long)((tiles + 1023.0) / 1024.0);
-            w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i] * (1.0 + 0.5 * (rc - r) / r);
-        } else {
-            // under one round: padded work, favouring more (smaller) tiles -- split-K fills the rest
-            w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i];
-            if (tiles < 512.0) w *= (512.0 / tiles) > 4.0 ? 4.0 : (512.0 / tiles);
-        }
         // 64x256 only where one row tile covers the problem (M <= 64, the 1.1 M-voxel layer1 / stem
-        // launches): on wider outputs a sweep of all configurations found it better on some mid-size
-        // layers and worse on as many -- not worth a table
+        // launches): on wider outputs the sweep found it better on some mid-size layers and worse on as many
         if (i == 5 && (prm.M > 64 || getenv("ZSV_NO_CFG5"))) continue;
+        const long tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
+        const long tn = ((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn;
+        const double tiles = (double)(tm * tn);
+        const double wgs = tiles * (double)tap_ksplit_for(tm * tn, nchunks);
+        double w = tiles * kTapCfgs[i].bm * kTapCfgs[i].bn * penalty[i];
+        if (wgs > 1024.0) {
+            const double r = wgs / 1024.0, rc = (double)(long)((wgs + 1023.0) / 1024.0);
+            w *= 1.0 + 0.3 * (rc - r) / r;
+        } else {
+            w *= pow(1024.0 / wgs, 0.4);
+        }
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
     if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % kNumTapCfgs;
@@ -372,19 +387,10 @@ int igemm_tap_stat_tiles(const IgemmParams& prm, const float* C) {
 }
 
 int igemm_tap_ksplit(const IgemmParams& prm) {
-    if (getenv("ZSV_NO_SPLITK")) return 1;
     int cfg, tiles_m, Mp, nblk, Cpad;
     tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);
     const long tiles = (long)tiles_m * (((long)prm.P + kTapCfgs[cfg].bn - 1) / kTapCfgs[cfg].bn);
-    const long nchunks = (long)prm.taps * nblk;
-    // 1024 workgroups are resident at once (256 CUs x 4); split K when one round is under-filled
-    long thresh = 700, target = 1024;
-    if (const char* e = getenv("ZSV_SPLITK_THRESH")) thresh = atol(e);
-    if (tiles >= thresh || nchunks < 32) return 1;
-    long ks = (target + tiles / 2) / tiles;              // nearest whole multiple of the tile count
-    if (ks > nchunks / 12) ks = nchunks / 12;            // >= 12 chunks per part
-    if (ks > 16) ks = 16;
-    return ks < 2 ? 1 : (int)ks;
+    return (int)tap_ksplit_for(tiles, (long)prm.taps * nblk);
 }
 
 int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c_stride, const float* G,
