@@ -344,6 +344,29 @@ struct WgradPlan {
     int Cpad, nblk, Kp;
 };
 
+// Slice count for `tiles` output tiles: one full round of resident workgroups (256 CUs x the
+// LDS-limited 2-4 per CU) -- every workgroup then runs start to finish concurrently and the slab
+// traffic is minimal.  Returns the round-fill efficiency of the best count (fewer slices on ties).
+static double wgrad_slices(long tiles, long chunks, int bp, int bm, int bn, long& slices) {
+    const long lds_bytes = (long)(bm + bn) * 34 * 4 * 2;
+    long per_cu = (160L * 1024) / lds_bytes;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    const long resident = 256L * per_cu;
+    long max_slices = (chunks * bp + 511) / 512;         // at least 512 voxels per slice
+    if (max_slices < 1) max_slices = 1;
+    if (max_slices > 1024) max_slices = 1024;
+    slices = 1;
+    double best_eff = -1.0;
+    for (long s = 1; s <= max_slices && tiles * s <= 4 * resident + tiles; ++s) {
+        const long wgs = tiles * s;
+        const long rounds = (wgs + resident - 1) / resident;
+        const double eff = (double)wgs / (double)(rounds * resident) - 0.02 * (double)wgs / (double)resident;
+        if (eff > best_eff + 1e-9) { best_eff = eff; slices = s; }
+    }
+    return best_eff;
+}
+
 static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     WgradPlan pl;
     const int M = d->Cout;
@@ -352,45 +375,36 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
     pl.Cpad = pl.nblk * 16;
     pl.Kp = taps * pl.Cpad;
     const long P = (long)d->N * d->To * d->Ho * d->Wo;
+    const int bp = wgrad_bp();
+    const long chunks = (P + bp - 1) / bp;
+    // Tile = the (rows, columns) pair with the least estimated time: padded MACs x a per-shape factor
+    // (narrow tiles issue fewer MFMAs per fragment read) / round-fill efficiency.  Factors fitted on a
+    // sweep of all 8 pairs over the R(2+1)D-18 layers at N = 22 (within 0.1 % of the per-layer best).
     const int bms[4] = {144, 128, 64, 80};
-    int best = 0;
+    const double pen_m[4] = {1.00, 1.00, 1.05, 1.08};
+    const int bns[2] = {128, 64};
+    const double pen_n[2] = {1.00, 1.10};
+    int best_m = 0, best_n = 0;
     double best_w = 1e300;
-    for (int i = 0; i < 4; ++i) {
-        const double w = (double)((M + bms[i] - 1) / bms[i]) * bms[i];
-        if (w < best_w * 0.999) { best_w = w; best = i; }
-    }
-    if (const char* e = getenv("ZSV_WGRAD_CFG")) best = atoi(e) & 3;
-    pl.cfg = best;
-    pl.bm = bms[best];
-    // 128 columns per tile unless 64 wastes clearly less of the last tile (Kp = 432: 512 vs 448)
-    pl.bn = 128;
-    if ((double)((pl.Kp + 63) / 64 * 64) * 1.12 < (double)((pl.Kp + 127) / 128 * 128)) pl.bn = 64;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const long tm = (M + bms[i] - 1) / bms[i], tn = (pl.Kp + bns[j] - 1) / bns[j];
+            long sl;
+            const double eff = wgrad_slices(tm * tn, chunks, bp, bms[i], bns[j], sl);
+            const double w = (double)(tm * bms[i]) * (double)(tn * bns[j]) * pen_m[i] * pen_n[j] / (eff > 1e-3 ? eff : 1e-3);
+            if (w < best_w * 0.999) { best_w = w; best_m = i; best_n = j; }
+        }
+    if (const char* e = getenv("ZSV_WGRAD_CFG")) best_m = atoi(e) & 3;
+    pl.cfg = best_m;
+    pl.bm = bms[best_m];
+    pl.bn = bns[best_n];
     if (const char* e = getenv("ZSV_WGRAD_BN")) pl.bn = atoi(e) == 64 ? 64 : 128;
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
-    const int bp = wgrad_bp();
-    const long chunks = (P + bp - 1) / bp;
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
-    // one full round of resident workgroups (256 CUs x LDS-limited 2-3 per CU): every workgroup
-    // then runs start to finish concurrently and the slab traffic is minimal
-    const long lds_bytes = (long)(pl.bm + pl.bn) * 34 * 4 * 2;
-    long per_cu = (160L * 1024) / lds_bytes;
-    if (per_cu > 4) per_cu = 4;
-    if (per_cu < 1) per_cu = 1;
-    const long resident = 256L * per_cu;
-    long max_slices = (chunks * bp + 511) / 512;         // at least 512 voxels per slice
-    if (max_slices < 1) max_slices = 1;
-    if (max_slices > 1024) max_slices = 1024;
-    // pick the slice count whose workgroup count fills whole rounds best (fewer slices on ties:
-    // less slab traffic)
-    long slices = 1;
-    double best_eff = -1.0;
-    for (long s = 1; s <= max_slices && tiles * s <= 4 * resident + tiles; ++s) {
-        const long wgs = tiles * s;
-        const long rounds = (wgs + resident - 1) / resident;
-        const double eff = (double)wgs / (double)(rounds * resident) - 0.02 * (double)wgs / (double)resident;
-        if (eff > best_eff + 1e-9) { best_eff = eff; slices = s; }
-    }
+    long slices;
+    wgrad_slices(tiles, chunks, bp, pl.bm, pl.bn, slices);
+    const long max_slices = ((chunks * bp + 511) / 512) < 1 ? 1 : ((chunks * bp + 511) / 512 > 1024 ? 1024 : (chunks * bp + 511) / 512);
     if (const char* e = getenv("ZSV_WGRAD_WGS")) slices = atol(e) / tiles;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
