@@ -186,13 +186,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_generic_kernel(WgradGenParams 
     }
 }
 
-// dw[i] = sum_s slab[s][i]  (slice order -> deterministic)
+// dw[i] = sum_s slab[s][i].  A block owns 32 elements x 8 slice groups (group g adds slices
+// g, g+8, ... in order; the 8 partials are then added in group order): fixed order, deterministic,
+// and the few thousand elements of a stem gradient still spread over the whole chip.
 __global__ __launch_bounds__(256) void slab_sum_generic_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        long n, int slices) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (long i0 = (long)blockIdx.x * 32; i0 < n; i0 += (long)gridDim.x * 32) {
+        const long i = i0 + e;
         float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * n + i];
-        out[i] = s;
+        if (i < n)
+            for (int k = g; k < slices; k += 8) s += slabs[(size_t)k * n + i];
+        part[g][e] = s;
+        __syncthreads();
+        if (g == 0 && i < n) {
+            float t = part[0][e];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += part[q][e];
+            out[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -260,8 +274,8 @@ int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     if (pl.slices > 1) {
         const long n = (long)p.M * p.K;
-        long blocks = (n + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        long blocks = (n + 31) / 32;
+        if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(slab_sum_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, pl.slices);
         if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     }
