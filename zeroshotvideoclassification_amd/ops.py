@@ -111,6 +111,7 @@ class _Conv3d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, relu, want_stats):
         _require(x, weight, bias)
+        ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) statistics output
         if x.dim() != 5 or weight.dim() != 5:
             raise RuntimeError("conv3d expects (N,C,T,H,W) input and (O,I,kT,kH,kW) weight")
         x = x.contiguous()
@@ -149,6 +150,8 @@ class _Conv3d(Function):
         x, weight, y = ctx.saved_tensors
         d = ctx.desc
         lib = _lib.load()
+        if dy is None:                          # output unused downstream
+            return None, None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dw = db = None
         with torch.cuda.device(dy.device):
@@ -282,6 +285,29 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, tra
                                float(eps), bool(relu), stats if training else None)
 
 
+_NBT_PENDING = None      # list of num_batches_tracked buffers to increment when the enclosing forward ends
+
+
+class batched_bn_counters:
+    """Within this context the ``num_batches_tracked += 1`` of every training-mode BatchNorm
+    (37 one-element kernels in R(2+1)D-18) is deferred and applied as one ``_foreach_add_`` on exit."""
+
+    def __enter__(self):
+        global _NBT_PENDING
+        self.outer = _NBT_PENDING
+        if self.outer is None:
+            _NBT_PENDING = []
+        return self
+
+    def __exit__(self, *exc):
+        global _NBT_PENDING
+        if self.outer is None:
+            pending, _NBT_PENDING = _NBT_PENDING, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+        return False
+
+
 def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None):
     """Apply an ``nn.BatchNorm3d``-like module's parameters through the fused kernel, with
     torch's train/eval and running-statistics semantics (momentum=None -> cumulative average
@@ -290,7 +316,10 @@ def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None)
         raise RuntimeError("cumulative-average BatchNorm (momentum=None) is not supported")
     use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append(bn.num_batches_tracked)         # one fused increment per forward
+        else:
+            bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
     rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
     return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu, stats)

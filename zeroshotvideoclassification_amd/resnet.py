@@ -219,11 +219,12 @@ class VideoResNet(nn.Module):
                     nn.init.zeros_(m.conv3[1].weight)
 
     def forward(self, x: Tensor):
-        x = self.stem(x)
-        x = self.layer1(x)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        f = self.layer4(x)
+        with ops.batched_bn_counters():
+            x = self.stem(x)
+            x = self.layer1(x)
+            x = self.layer2(x)
+            x = self.layer3(x)
+            f = self.layer4(x)
         pooled = ops.mean_pool(f)          # avgpool + flatten(1); `fc` is skipped by the fork
         return pooled, f
 
