@@ -393,3 +393,41 @@ def test_batchnorm_and_pool_edge_shapes():
         out = ops.batch_norm_act(x.to(DEV), None, None, None, None, None, True, 0.1, 1e-5, False)
         close(out, ref, rtol=1e-4, what=f"bn {shape}")
         close(ops.mean_pool(x.to(DEV)), x.double().mean(dim=(2, 3, 4)), what=f"meanpool {shape}")
+
+
+WGRAD_DMA_CASES = [
+    # stride 1, equal extents, T*H*W % 16 == 0, Cin >= 16: the LDS-DMA weight-gradient kernel
+    # name, N, Cin, (T,H,W), Cout, kernel, padding
+    ("s1_like", 2, 64, (2, 12, 12), 144, (1, 3, 3), (0, 1, 1)),           # row tile 144
+    ("t1_like", 3, 144, (4, 8, 8), 64, (3, 1, 1), (1, 0, 0)),             # 3 clips: clip wrap inside a slice
+    ("cin_45", 2, 45, (4, 4, 4), 64, (3, 1, 1), (1, 0, 0)),               # channel padding 45 -> 48
+    ("cout_230", 1, 32, (2, 8, 8), 230, (1, 3, 3), (0, 1, 1)),            # ragged row tiles
+    ("full_333", 2, 16, (4, 4, 4), 40, (3, 3, 3), (1, 1, 1)),             # 27 taps
+    ("one_chunk", 1, 16, (1, 4, 4), 16, (1, 3, 3), (0, 1, 1)),            # a single 16-voxel chunk
+    ("wide_w", 1, 24, (1, 4, 20), 20, (1, 3, 3), (0, 1, 1)),              # W not a multiple of 4: unaligned row shifts
+    ("pointwise", 2, 64, (2, 4, 4), 128, (1, 1, 1), (0, 0, 0)),           # 1 tap, no border
+    ("many_slices", 6, 32, (8, 16, 16), 48, (1, 3, 3), (0, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_DMA_CASES, ids=[c[0] for c in WGRAD_DMA_CASES])
+def test_conv3d_wgrad_dma_path(case, monkeypatch):
+    name, n, cin, (t, h, w), cout, k, p = case
+    g = torch.Generator().manual_seed(hash(name) % 2**31)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * np.prod(k))
+    xr, wr = x.double(), wt.double().requires_grad_()
+    yr = F.conv3d(xr, wr, padding=p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    def run():
+        wg = wt.to(DEV).requires_grad_()
+        ops.conv3d(x.to(DEV), wg, None, 1, p).backward(dy.to(DEV))
+        return wg.grad
+
+    a = run()
+    close(a, wr.grad, what=f"{name} wgrad (dma)")
+    assert torch.equal(a, run()), "bitwise reproducible"
+    monkeypatch.setenv("ZSV_NO_WGRAD_DMA", "1")                     # the register-staged kernel on the same problem
+    close(run(), wr.grad, what=f"{name} wgrad (register-staged)")

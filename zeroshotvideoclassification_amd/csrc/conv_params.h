@@ -166,5 +166,11 @@ int conv_check(const zsv_conv_desc* d);
 size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                   size_t workspace_bytes, hipStream_t stream);
+// LDS-DMA weight gradient of stride-1 "same" convolutions (conv_wgrad_dma.hip): writes the per-slice
+// slabs [slice][Cout][taps*Cpad] at the start of `workspace`
+bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
+size_t wgrad_dma_workspace_bytes(const zsv_conv_desc* d);
+int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* workspace, size_t workspace_bytes,
+              int* slices_out, int* cpad_out, hipStream_t stream);
 
 }  // namespace zsv

@@ -440,7 +440,12 @@ extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
     if (d->Cin < 16) return wgrad_generic_workspace_bytes(d);
     const WgradPlan pl = wgrad_plan(d);
-    return (size_t)pl.slices * d->Cout * pl.Kp * sizeof(float);
+    size_t need = (size_t)pl.slices * d->Cout * pl.Kp * sizeof(float);
+    if (wgrad_dma_applicable(d, nullptr, nullptr)) {        // (the pointer alignment decides at call time)
+        const size_t b = wgrad_dma_workspace_bytes(d);
+        if (b > need) need = b;
+    }
+    return need;
 }
 
 extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -453,6 +458,18 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     const WgradPlan pl = wgrad_plan(d);
     const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
+    if (wgrad_dma_applicable(d, x, dy)) {
+        int slices = 0, cpad = 0;
+        st = wgrad_dma(d, x, dy, workspace, workspace_bytes, &slices, &cpad, stream);
+        if (st) return st;
+        const int taps = d->kT * d->kH * d->kW;
+        const long n = (long)d->Cout * taps * cpad;
+        long blocks = (n + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, d->Cout,
+                           d->Cin, taps, cpad, slices);
+        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+    }
 
     WgradParams p;
     p.M = d->Cout;
