@@ -316,22 +316,36 @@ __global__ __launch_bounds__(256, (BP == 16 ? 3 : 2)) void conv_wgrad_kernel(Wgr
     }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][co][tap * Cpad + ci]   (slice order -> deterministic).
-// Threads walk the slab order (ci fastest) so the `slices` reads per element are coalesced; the
-// single strided write per element is 1/slices of the traffic.
+// dw[co][ci][tap] = sum_s slab[s][co][tap * Cpad + ci].  A block owns 32 consecutive slab elements (ci
+// fastest: coalesced reads) x 8 slice groups: group g adds slices g, g+8, ... in order, the 8 partials
+// are added in group order -- a fixed order, so bitwise reproducible, with 8x the loads in flight of a
+// one-thread-per-element loop (the ~250 slices of a layer1 gradient made that loop latency-bound).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                        int M, int Cin, int taps, int Cpad, int slices) {
+    __shared__ float part[8][32];
     const size_t slab = (size_t)M * taps * Cpad;
-    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < slab; j += (size_t)gridDim.x * 256) {
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (size_t j0 = (size_t)blockIdx.x * 32; j0 < slab; j0 += (size_t)gridDim.x * 32) {
+        const size_t j = j0 + e;
         const int ci = (int)(j % Cpad);
-        if (ci >= Cin) continue;
-        const size_t r = j / Cpad;
-        const int tap = (int)(r % taps);
-        const int co = (int)(r / taps);
-        const float* src = slabs + j;
+        const bool live = j < slab && ci < Cin;
         float s = 0.f;
-        for (int k = 0; k < slices; ++k) s += src[(size_t)k * slab];
-        out[((size_t)co * Cin + ci) * taps + tap] = s;
+        if (live) {
+            const float* src = slabs + j;
+            for (int k = g; k < slices; k += 8) s += src[(size_t)k * slab];
+        }
+        part[g][e] = s;
+        __syncthreads();
+        if (g == 0 && live) {
+            float t = part[0][e];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += part[q][e];
+            const size_t r = j / Cpad;
+            const int tap = (int)(r % taps);
+            const int co = (int)(r / taps);
+            out[((size_t)co * Cin + ci) * taps + tap] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -464,8 +478,8 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
         if (st) return st;
         const int taps = d->kT * d->kH * d->kW;
         const long n = (long)d->Cout * taps * cpad;
-        long blocks = (n + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
+        long blocks = (n + 31) / 32;
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, d->Cout,
                            d->Cin, taps, cpad, slices);
         return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
@@ -508,8 +522,8 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     }
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const long n = (long)p.M * p.taps * pl.Cpad;
-    long blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    long blocks = (n + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, p.M,
                        p.Cin, p.taps, pl.Cpad, pl.slices);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
