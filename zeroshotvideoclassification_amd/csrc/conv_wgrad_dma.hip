@@ -75,7 +75,7 @@ __global__ void wgrad_vmask_kernel(int S, int T, int H, int W, int kT, int kH, i
 // KB = 16-voxel chunks per barrier (2 for the small tiles, whose 16-32 MFMAs per chunk would otherwise be
 // shorter than the barrier + DMA turn-around)
 template <int TM, int TN, int KB>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(WgradDmaParams prm, const float* __restrict__ X,
+__global__ __launch_bounds__(256, (TM * TN > 27 ? 2 : 3)) void conv_wgrad_dma_kernel(WgradDmaParams prm, const float* __restrict__ X,
                                                                 const float* __restrict__ DY,
                                                                 const unsigned* __restrict__ VM,
                                                                 float* __restrict__ OUT) {
@@ -295,21 +295,21 @@ static WgradDmaPlan wgrad_dma_plan(const zsv_conv_desc* d) {
     // often than of 128 (576 = 3 x 192, 432 -> 448 = 7 x 64)
     const int tms[4] = {9, 8, 4, 5};
     const double pen_m[4] = {1.00, 1.00, 1.05, 1.08};
-    const int tns[3] = {2, 3, 1};
-    const double pen_n[3] = {1.00, 1.00, 1.06};
+    const int tns[4] = {2, 3, 1, 7};                    // 7: a 64-row problem with <= 448 columns in ONE tile (dY read once)
+    const double pen_n[4] = {1.00, 1.00, 1.06, 1.00};
     long max_slices = (chunks * 16 + 511) / 512;         // at least 512 voxels per slice
     if (max_slices < 1) max_slices = 1;
     if (max_slices > 1024) max_slices = 1024;
     double best_w = 1e300;
     pl.tm = 9; pl.tn = 2; pl.slices = 1;
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int bm = 16 * tms[i], bn = 64 * tns[j];
-            if (tms[i] * tns[j] > 27) continue;          // accumulator registers
+            if (tms[i] * tns[j] > 28) continue;          // accumulator registers
             const long tm_ = (M + bm - 1) / bm, tn_ = (pl.Kp + bn - 1) / bn, tiles = tm_ * tn_;
             const long lds = 2L * (tms[i] * tns[j] <= 10 ? 2 : 1) * ((bm + bn) * 64 + 1024);
             long per_cu = (160L * 1024) / lds;
-            const long by_regs = 3;                       // __launch_bounds__(256, 3)
+            const long by_regs = tms[i] * tns[j] > 27 ? 2 : 3;     // __launch_bounds__
             if (per_cu > by_regs) per_cu = by_regs;
             const long resident = 256L * per_cu;
             long sl = 1;
@@ -323,7 +323,7 @@ static WgradDmaPlan wgrad_dma_plan(const zsv_conv_desc* d) {
             if (w < best_w * 0.999) { best_w = w; pl.tm = tms[i]; pl.tn = tns[j]; pl.slices = (int)sl; }
         }
     if (const char* e = getenv("ZSV_WGRAD_DMA_TM")) { const int t = atoi(e); if (t == 9 || t == 8 || t == 4 || t == 5) pl.tm = t; }
-    if (const char* e = getenv("ZSV_WGRAD_DMA_TN")) { const int t = atoi(e); if (t >= 1 && t <= 3 && t * pl.tm <= 27) pl.tn = t; }
+    if (const char* e = getenv("ZSV_WGRAD_DMA_TN")) { const int t = atoi(e); if ((t >= 1 && t <= 3 && t * pl.tm <= 27) || (t == 7 && pl.tm == 4)) pl.tn = t; }
     const int bm = 16 * pl.tm, bn = 64 * pl.tn;
     pl.tiles_m = (M + bm - 1) / bm;
     pl.tiles_n = (pl.Kp + bn - 1) / bn;
@@ -360,6 +360,9 @@ template <int TM>
 static int wgrad_dma_launch_tn(int tn, const WgradDmaParams& p, int slices, hipStream_t stream, const float* x,
                                const float* dy, const unsigned* vm, float* out) {
     if (tn == 1) return wgrad_dma_launch<TM, 1>(p, slices, stream, x, dy, vm, out);
+    if constexpr (TM == 4) {
+        if (tn == 7) return wgrad_dma_launch<TM, 7>(p, slices, stream, x, dy, vm, out);
+    }
     if constexpr (TM * 3 <= 27) {
         if (tn == 3) return wgrad_dma_launch<TM, 3>(p, slices, stream, x, dy, vm, out);
     }
