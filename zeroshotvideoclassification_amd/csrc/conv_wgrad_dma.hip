@@ -38,6 +38,7 @@ struct WgradDmaParams {
     int S, HW, W;                     // voxels per clip / frame / row (input extents = output extents)
     int kH, kW, pT, pH, pW;
     int chunks_total, chunks_per_slice;      // 16-voxel chunks
+    int walk_T;                               // > 0: chunks walk the T frames of one 16-voxel (h,w) segment first
     long x_elems;
     int tiles_m, tiles_mn;
 };
@@ -94,8 +95,20 @@ __global__ __launch_bounds__(256, (TM * TN > 27 ? 2 : 3)) void conv_wgrad_dma_ke
     const int m0 = tm * BM, n0 = tn * BN;
     const int c0 = slice * prm.chunks_per_slice;
     const int nq = min(prm.chunks_per_slice, prm.chunks_total - c0);
-    int n_img = (c0 * 16) / prm.S;
-    int p_local = c0 * 16 - n_img * prm.S;
+    // Chunk order inside a clip.  Linear (walk_T = 0), or -- for kernels with temporal taps -- frame-minor:
+    // the T frames of one 16-voxel (h,w) segment, then the next segment, so that the rows a tap reads at
+    // frame t-1 / t+1 are the rows the neighbouring chunks just fetched (x then comes from HBM once, not kT times).
+    const int cpc = prm.S / 16;                       // chunks per clip
+    int n_img = c0 / cpc;
+    int w_t = 0, w_seg = 0, p_local;
+    if (prm.walk_T > 0) {
+        const int cin = c0 - n_img * cpc;
+        w_seg = cin / prm.walk_T;
+        w_t = cin - w_seg * prm.walk_T;
+        p_local = w_t * prm.HW + w_seg * 16;
+    } else {
+        p_local = (c0 - n_img * cpc) * 16;
+    }
 
     // ---- DMA assignment: lane l of a piece fills row l/4, slot l%4 <- source slot (l%4) ^ swz(row) ----
     const int srcslot = ((lane & 3) ^ swz64(lane >> 2)) * 4;
@@ -144,13 +157,24 @@ __global__ __launch_bounds__(256, (TM * TN > 27 ? 2 : 3)) void conv_wgrad_dma_ke
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(base + b_dst[k]), 16, 0, 0);
         }
         __builtin_amdgcn_global_load_lds(VM + p_local + vm_lane, (lds_ptr_t)(base + VM_AT + wave * 256), 4, 0, 0);
-        // next chunk: 16 voxels on, or the first voxels of the next clip
-        p_local += 16;
-        long ja = 16, jb = 16;
-        if (p_local == prm.S) {
-            p_local = 0;
-            ja += (long)(prm.M - 1) * prm.S;
-            jb += (long)(prm.Cin - 1) * prm.S;
+        // next chunk: 16 voxels on (or the same segment one frame on), or the first voxels of the next clip
+        int np;
+        bool wrap = false;
+        if (prm.walk_T > 0) {
+            if (++w_t == prm.walk_T) {
+                w_t = 0;
+                if ((++w_seg) * 16 == prm.HW) { w_seg = 0; wrap = true; }
+            }
+            np = w_t * prm.HW + w_seg * 16;
+        } else {
+            np = p_local + 16;
+            if (np == prm.S) { np = 0; wrap = true; }
+        }
+        long ja = np - p_local, jb = np - p_local;
+        p_local = np;
+        if (wrap) {
+            ja += (long)prm.M * prm.S;
+            jb += (long)prm.Cin * prm.S;
         }
 #pragma unroll
         for (int k = 0; k < NAW; ++k) a_ptr[k] += a_step[k] ? ja : 0;
@@ -379,6 +403,7 @@ int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* wor
     p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi;
     p.kH = d->kH; p.kW = d->kW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.chunks_total = (int)((long)d->N * p.S / 16);
+    p.walk_T = (d->kT > 1 && d->Ti > 1 && p.HW % 16 == 0 && getenv("ZSV_WGRAD_LINEAR_WALK") == nullptr) ? d->Ti : 0;
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_elems = (long)d->N * d->Cin * p.S;
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
