@@ -48,6 +48,9 @@ CASES = [
     (1, 512, 1152, (2, 7, 7), (1, 3, 3), (1, 1, 1), (0, 1, 1), False, True),     # layer4 width
     (1, 921, 512, (2, 4, 4), (3, 1, 1), (1, 1, 1), (1, 0, 0), True, True),       # 921 -> pitch 928, ragged voxel tile
     (5, 32, 33, (1, 3, 3), (1, 3, 3), (1, 1, 1), (0, 1, 1), False, False),       # tiny, Cout just over one chunk
+    (2, 144, 64, (8, 8, 8), (3, 1, 1), (1, 1, 1), (1, 0, 0), True, True),        # temporal, frames-x-positions tiles (8 x 32)
+    (1, 45, 64, (16, 8, 12), (3, 1, 1), (1, 1, 1), (1, 0, 0), False, True),      # same, two frame blocks per clip
+    (8, 32, 128, (16, 28, 28), (3, 1, 1), (1, 1, 1), (1, 0, 0), True, False),    # 16 frames x 16 positions, 128-row tiles
 ]
 
 

@@ -133,11 +133,14 @@ __device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, uns
 
 // + shift (+ residual), relu, bf16, channels-last stores (16 bytes per lane for paired row blocks);
 // `sh` = this row tile's shifts in LDS.
+// Column c of the tile is voxel n0 + c, or -- hb_shift > 0, the (frames x positions) tiles of
+// conv_bf16_tsame_kernel -- voxel n0 + (c >> hb_shift) * frame_stride + (c & (HB - 1)).
 template <int TM, int TN, int BM, int BN>
 __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM][TN], const float* sh,
                                          const __bf16* __restrict__ R, __bf16* __restrict__ Y, int m0, int n0, int tm,
-                                         int wm, int wn, int tid) {
+                                         int wm, int wn, int tid, int hb_shift = 0, int frame_stride = 0) {
     const int lane = tid & 63;
+    auto voxel = [&](int c) { return hb_shift ? n0 + (c >> hb_shift) * frame_stride + (c & ((1 << hb_shift) - 1)) : n0 + c; };
     const float floor_ = prm.relu ? 0.f : -__builtin_inff();
     const int g = lane >> 4;
     const int ch_t = wm * TM * 16;                   // this wave's first channel inside the row tile
@@ -146,7 +149,7 @@ __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM]
         constexpr bool HAS_RES = decltype(has_res)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 16 + (lane & 15);
+            const int col = voxel((wn * TN + j) * 16 + (lane & 15));
             const bool cv = col < prm.P;
             const size_t row_off = (size_t)(cv ? col : 0) * prm.CoutP + m0;
             u32x4 res[NPAIR > 0 ? NPAIR : 1];
@@ -200,7 +203,7 @@ __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM]
         const int per_col = (prm.CoutP - covered) >> 2;            // 8-byte pieces per voxel
         for (int idx = tid; idx < BN * per_col; idx += 256) {
             const int c = idx / per_col, k = idx - c * per_col;
-            const int col = n0 + c;
+            const int col = voxel(c);
             if (col < prm.P) *(u32x2*)(Y + (size_t)col * prm.CoutP + covered + 4 * k) = u32x2{0u, 0u};
         }
     }
@@ -504,6 +507,138 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
 #endif
 }
 
+// Temporal 3x1x1 stride-1 convolutions (Conv2Plus1D's second half, resnet.py:50-52): the workgroup tile
+// is TT output frames x HB (h,w) positions (TT * HB = 256 columns), so ONE LDS image of TT+2 input
+// frames x HB positions serves the three taps -- a tap is a shift of HB rows, always 16-row aligned --
+// and the input crosses L2 -> LDS 1.25x (TT = 8) instead of 3x.  A frame outside the clip is a zero
+// image row block; the test is uniform per 16-column block.  Steps = (chunk, kt): A ring of 3 per step,
+// image ring of 2 per chunk, as in conv_bf16_same_kernel.
+template <int TM, int TN, int WGM, int WGN, int TT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_tsame_kernel(Bf16Params prm, const __bf16* __restrict__ X,
+                                                                 const __bf16* __restrict__ Wp,
+                                                                 const float* __restrict__ shift,
+                                                                 const __bf16* __restrict__ R, __bf16* __restrict__ Y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WGM == 1 && WGN == 4 && TN == 4, "256 columns = 4 waves x 4 blocks");
+    constexpr int KT = 3;
+    constexpr int BM = 16 * TM, BN = 256, HB = BN / TT;
+    constexpr int HB_SHIFT = HB == 32 ? 5 : 4;
+    static_assert(HB == 32 || HB == 16, "positions per frame row block");
+    constexpr int NA_P = BM / 16, NI_P = (TT + 2) * HB / 16;
+    constexpr int NAW = (NA_P + 3) / 4, NIW = (NI_P + 3) / 4;
+    constexpr int A_STAGE = BM * 64, IMG = NI_P * 1024;
+    constexpr int IMG_AT = 3 * A_STAGE, SHIFT_AT = IMG_AT + 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int tm = tile % prm.tiles_m, tn = tile / prm.tiles_m;
+    const int m0 = tm * BM;
+    // column tile -> (clip, frame block, position block); positions fastest
+    const int T = prm.Ti, HW = prm.HoWo;
+    const int hbs = HW / HB, tbs = T / TT;
+    const int hb = tn % hbs, tb = (tn / hbs) % tbs, n = tn / (hbs * tbs);
+    const int t0 = tb * TT, hw0 = hb * HB;
+    const int n0 = (n * T + t0) * HW + hw0;          // voxel of column 0
+
+    const int srcslot = ((lane & 3) ^ swz(lane >> 2)) * 8;
+    int a_off[NAW], a_dst[NAW];
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        int pa = wave + 4 * k;
+        if (pa >= NA_P) pa -= 4;
+        a_off[k] = (pa * 16 + (lane >> 2)) * 32 + srcslot;
+        a_dst[k] = pa * 1024;
+    }
+    long i_src[NIW];                                 // element offset of this lane's image row (chunk 0), or -1
+    int i_dst[NIW];
+#pragma unroll
+    for (int k = 0; k < NIW; ++k) {
+        int pi = wave + 4 * k;
+        if (pi >= NI_P) pi -= 4;
+        const int r = pi * 16 + (lane >> 2);
+        const int tin = t0 - 1 + (r >> HB_SHIFT);
+        i_src[k] = (unsigned)tin < (unsigned)T ? ((long)(n * T + tin) * HW + hw0 + (r & (HB - 1))) * prm.sW + srcslot : -1;
+        i_dst[k] = pi * 1024;
+    }
+    // validity of tap kt for this wave's column block j: output frame t0 + ((wave*4+j)*16 >> HB_SHIFT)
+    unsigned keep[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int tf = t0 + (((wave * TN + j) * 16) >> HB_SHIFT);
+        unsigned m = 0;
+        for (int a = 0; a < KT; ++a) m |= (unsigned)((unsigned)(tf + a - 1) < (unsigned)T) << a;
+        keep[j] = m;
+    }
+    const __bf16* zero = (const __bf16*)zsv_zero_line;
+    const size_t wq_step = (size_t)prm.Mp * 32;
+    const __bf16* w_tile = Wp + (size_t)m0 * 32;
+
+    const int nimg = prm.nchunk, nsteps = nimg * KT;
+    int a_cc = 0, a_kt = 0;
+    auto issue_a = [&](int buf) {
+        const __bf16* wq = w_tile + (size_t)(a_kt * prm.nchunk + a_cc) * wq_step;
+        unsigned char* base = lds + buf * A_STAGE;
+#pragma unroll
+        for (int k = 0; k < NAW; ++k) __builtin_amdgcn_global_load_lds(wq + a_off[k], (lds_ptr_t)(base + a_dst[k]), 16, 0, 0);
+        if (++a_kt == KT) { a_kt = 0; ++a_cc; }
+    };
+    int b_cc = 0;
+    auto issue_b = [&](int buf) {
+        unsigned char* base = lds + IMG_AT + buf * IMG;
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const __bf16* ptr = i_src[k] >= 0 ? X + (i_src[k] + b_cc * 32) : zero;
+            __builtin_amdgcn_global_load_lds(ptr, (lds_ptr_t)(base + i_dst[k]), 16, 0, 0);
+        }
+        ++b_cc;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned frag = (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    const unsigned a_frag = lds_base + frag;
+    const unsigned b_frag = lds_base + IMG_AT + wave * TN * 1024 + frag;      // + kt * HB rows per tap
+
+    if (wave == 0) {
+        const int l4 = lane < BM / 4 ? lane : BM / 4 - 1;
+        __builtin_amdgcn_global_load_lds(shift + m0 + 4 * l4, (lds_ptr_t)(lds + SHIFT_AT), 16, 0, 0);
+    }
+    issue_b(0);
+    issue_a(0);
+    issue_a(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int abuf = 0, abuf2 = 2;
+    for (int img = 0; img < nimg; ++img) {
+        const unsigned img_off = (img & 1) * IMG;
+#pragma unroll
+        for (int c = 0; c < KT; ++c) {
+            const int step = img * KT + c;
+            const bool more_a = step + 2 < nsteps;
+            const bool more_b = c == 0 && img + 1 < nimg;
+            if (more_a) issue_a(abuf2);
+            if (more_b) issue_b((img + 1) & 1);
+            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag + img_off + c * HB * 64, (keep[0] >> c) & 1u,
+                                    (keep[1] >> c) & 1u, (keep[2] >> c) & 1u, (keep[3] >> c) & 1u);
+            if (c < KT - 1 && more_a && img + 1 < nimg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW + NIW) : "memory");
+            else if (c == KT - 1 && more_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            abuf = abuf == 2 ? 0 : abuf + 1;
+            abuf2 = abuf2 == 2 ? 0 : abuf2 + 1;
+        }
+    }
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, 0, wave, tid, HB_SHIFT, HW);
+#endif
+}
+
 // Wp[q][Mp][32] <- w[Cout][Cin][kT][kH][kW] * scale[cout]; then Mp fp32 shifts.
 __global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                  const float* __restrict__ shift, __bf16* __restrict__ wp, float* __restrict__ shift_out,
@@ -638,6 +773,32 @@ static bool bf16_same_applicable(const zsv_conv_desc* d) {
            d->Ho == d->Hi && d->Wo == d->Wi && getenv("ZSV_BF16_NO_SAME") == nullptr;
 }
 
+template <int TM, int TT>
+static int bf16_tsame_launch(Bf16Params& p, const zsv_conv_desc* d, hipStream_t stream, const __bf16* x, const __bf16* wp,
+                             const float* shift, const __bf16* r, __bf16* y) {
+    constexpr int BM = 16 * TM, HB = 256 / TT;
+    constexpr int LDS_BYTES = 3 * BM * 64 + 2 * ((TT + 2) * HB / 16) * 1024 + 1024;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_bf16_tsame_kernel<TM, 4, 1, 4, TT>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    p.tiles_m = p.Mp / BM;
+    p.tiles_n = d->N * (d->Ti / TT) * (d->Hi * d->Wi / HB);
+    hipLaunchKernelGGL((conv_bf16_tsame_kernel<TM, 4, 1, 4, TT>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, stream, p,
+                       x, wp, shift, r, y);
+    return launch_status();
+}
+
+// 3x1x1, stride 1, pad (1,0,0): frames-x-positions tiles if the clip divides into them; returns TT or 0
+static int bf16_tsame_frames(const zsv_conv_desc* d) {
+    if (bf16_folded(d) || d->kT != 3 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 1 ||
+        d->pH != 0 || d->pW != 0 || getenv("ZSV_BF16_NO_TSAME"))
+        return 0;
+    const int HW = d->Hi * d->Wi;
+    if (d->Ti % 8 == 0 && HW % 32 == 0) return 8;
+    if (d->Ti % 16 == 0 && HW % 16 == 0) return 16;
+    return 0;
+}
+
 }  // namespace zsv
 
 using namespace zsv;
@@ -703,6 +864,12 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     __bf16* yb = (__bf16*)y;
     hipStream_t s = (hipStream_t)stream;
     const bool small = (long)(p.Mp / 128) * ((p.P + 255) / 256) < 384;      // too few 128x256 tiles to fill the chip
+    if (const int tt = bf16_tsame_frames(d); tt != 0 && (bm == 64 || (bm == 128 && !small))) {
+        if (bm == 64) return tt == 8 ? bf16_tsame_launch<4, 8>(p, d, s, xb, wp, shift, rb, yb)
+                                     : bf16_tsame_launch<4, 16>(p, d, s, xb, wp, shift, rb, yb);
+        return tt == 8 ? bf16_tsame_launch<8, 8>(p, d, s, xb, wp, shift, rb, yb)
+                       : bf16_tsame_launch<8, 16>(p, d, s, xb, wp, shift, rb, yb);
+    }
     // (the 64-row wave tiles of the small-P configuration have too few MFMAs per step to hide the
     // fragment masking of the shared-image kernel: measured slower there)
     if (bf16_same_applicable(d) && bm != 64 && !(bm == 128 && small)) {
