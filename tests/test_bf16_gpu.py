@@ -185,3 +185,25 @@ def test_engine_ranking_agrees_with_fp32():
     assert (top[:, 0] == top_ref[:, 0]).float().mean().item() >= 0.75
     overlap = np.mean([len(set(a.tolist()) & set(b.tolist())) for a, b in zip(top, top_ref)])
     assert overlap >= 4.0
+
+
+def test_evaluate_protocol_in_bf16():
+    """train.evaluate(dtype=bf16) = the fp32 protocol (main.py:224-325) with the engine's forward."""
+    model = _model("r2plus1d_18", seed=5)
+    table = synthetic.class_table(51)
+    batches = []
+    for i in range(2):
+        x = synthetic.synthetic_clips(4, 8, 64, seed=300 + i)
+        labels, z = synthetic.synthetic_targets(4, 51, rank=i)
+        batches.append((x, labels, z))
+    a = train.evaluate(model, batches, table, device=torch.device(DEV), splits=2)
+    b = train.evaluate(model, batches, table, device=torch.device(DEV), splits=2, dtype=torch.bfloat16)
+    assert a["n"] == b["n"] == 8
+    eng = inference.engine_for(model)
+    assert inference.engine_for(model) is eng, "engine is cached while the weights are unchanged"
+    with torch.no_grad():
+        model.model.stem[0].weight.mul_(1.0)
+    assert inference.engine_for(model) is not eng, "a write to a trunk parameter invalidates it"
+    assert abs(a["accuracy_top5"] - b["accuracy_top5"]) <= 12.5 + 1e-6         # at most one of 8 clips flips
+    with pytest.raises(RuntimeError, match="not supported"):
+        train.evaluate(model, batches, table, device=torch.device(DEV), dtype=torch.float16)

@@ -2,9 +2,9 @@
 """Config E geometry: the reference's `evaluate()` protocol (main.py:224-325) on
 32-frame clips -- eval-mode forward under no_grad + cosine nearest-class search against the three
 "kinetics2others" class tables (UCF101 101, HMDB51 51, ActivityNet 200 classes; dataset.py:34-90),
-synthetic clips and unit-norm class tables.  fp32 (a bf16 path does not exist yet).
+synthetic clips and unit-norm class tables.
 
-    python tools/eval_bench.py [--batch 22] [--frames 32] [--batches 6]
+    python tools/eval_bench.py [--batch 22] [--frames 32] [--batches 6] [--dtype fp32|bf16]
 """
 import argparse
 import json
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=22)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--batches", type=int, default=6)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     model = network.get_network(SimpleNamespace(network="r2plus1d_18", fixconvs=False, nopretrained=False))
@@ -37,15 +38,16 @@ def main():
             x = synthetic.synthetic_clips(args.batch, args.frames, 112, seed=7000 + i).to(dev)
             labels, z = synthetic.synthetic_targets(args.batch, ncls, seed=1000 + ncls, rank=i)
             batches.append((x, labels, z))
-        train.evaluate(model, batches[:1], table, device=dev, splits=0)          # warm-up
+        dt_ = torch.bfloat16 if args.dtype == "bf16" else None
+        train.evaluate(model, batches[:1], table, device=dev, splits=0, dtype=dt_)          # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = train.evaluate(model, batches, table, device=dev)
+        res = train.evaluate(model, batches, table, device=dev, dtype=dt_)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res["clips_per_s"] = round(res["n"] / dt, 1)
         results[name] = res
-    print(json.dumps({"metric": "eval clips/s, R(2+1)D-18, 32x112x112, fp32, eval-mode BN + cosine NN",
+    print(json.dumps({"metric": f"eval clips/s, R(2+1)D-18, 32x112x112, {args.dtype}, eval-mode BN + cosine NN",
                       "batch": args.batch, "frames": args.frames, "results": results}))
 
 

@@ -238,3 +238,16 @@ class Bf16Engine:
         pooled = self.trunk(clips)
         emb = self.model.output2emb_proj(pooled)                       # network.py:595 (mean already taken)
         return F.normalize(emb, dim=-1), None                          # network.py:596,600
+
+
+def engine_for(model: nn.Module) -> Bf16Engine:
+    """The model's bf16 engine, rebuilt only when a trunk parameter or BatchNorm buffer has been written
+    since it was built (tensor version counters), e.g. once per epoch for the three test sets of
+    main.py:352-358."""
+    own = getattr(model, "module", model)
+    key = tuple(t._version for t in list(own.model.parameters()) + list(own.model.buffers()))
+    cached = getattr(own, "_zsv_bf16_engine", None)
+    if cached is None or cached[0] != key:
+        cached = (key, Bf16Engine(own))
+        own._zsv_bf16_engine = cached
+    return cached[1]

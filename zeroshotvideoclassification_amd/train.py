@@ -94,12 +94,20 @@ def compute_accuracy(predicted_embed: torch.Tensor, class_embed: torch.Tensor,
 
 @torch.no_grad()
 def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], class_embed: torch.Tensor,
-             device: Optional[torch.device] = None, splits: int = 10) -> dict:
+             device: Optional[torch.device] = None, splits: int = 10, dtype: Optional[torch.dtype] = None) -> dict:
     """main.py:224-313 for one test set.  ``batches`` yields ``(X, labels, Z, ...)``; samples with
-    label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248."""
+    label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248.
+    ``dtype=torch.bfloat16`` runs the forward on the bf16 engine (``inference.Bf16Engine``, the
+    reduced-precision eval of BASELINE config 5 / the reference's autocast, main.py:172); default fp32."""
     was_training = model.training
     model.eval()
     device = device or next(model.parameters()).device
+    forward = model
+    if dtype == torch.bfloat16:
+        from .inference import engine_for
+        forward = engine_for(model)
+    elif dtype not in (None, torch.float32):
+        raise RuntimeError(f"evaluate: dtype {dtype} is not supported (fp32 or bf16)")
     preds, trues, labels = [], [], []
     for batch in batches:
         x, l, z = batch[0], batch[1], batch[2]
@@ -107,11 +115,13 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
         if keep.sum() == 0:
             continue
         x, l, z = x[keep], l[keep], z[keep]
-        preds.append(embed(model, x.to(device)).float())
-        trues.append(z.to(device).float().reshape(len(l), -1))
+        preds.append(embed(forward, x.to(device, non_blocking=True)).float())
+        # targets / labels join the device once, after the loop: a per-batch blocking copy would drain the
+        # queue every batch (and an idle-then-busy GPU showed sporadic 30-80 ms stalls on the test pool)
+        trues.append(z.float().reshape(len(l), -1))
         labels.append(l.reshape(-1))
     model.train(was_training)
-    pred, true = torch.cat(preds), torch.cat(trues)
+    pred, true = torch.cat(preds), torch.cat(trues).to(device)
     label = torch.cat(labels).cpu().numpy()
     class_embed = class_embed.to(device)
     acc, acc5 = compute_accuracy(pred, class_embed, true)
