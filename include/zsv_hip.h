@@ -70,6 +70,13 @@ int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const
 size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv3d_input_grad(dy, w) + add: the gradient arriving over an identity shortcut
+ * (`out += residual`, resnet.py:108-110, residual = the convolution's own input) is added in the
+ * epilogue instead of by a separate pass.  Only where zsv_conv3d_dgrad_add_supported(d) != 0 (stride 1,
+ * no split-K); `add` has dx's shape; add == NULL = zsv_conv3d_dgrad. */
+int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d);
+int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* dw = conv3d_weight_grad(x, dy).  Deterministic: position range is cut into a fixed
  * number of slices, each slice writes a partial slab into `workspace`, a second kernel
  * sums the slabs in slice order. */

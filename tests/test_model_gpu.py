@@ -323,3 +323,39 @@ def test_training_loop_converges_like_the_oracle():
     for a, b in zip(lg[:6], lc):
         assert abs(a / b - 1) < 0.10, (lg[:6], lc)
     assert lg[-1] < 0.2 * lg[0], lg
+
+
+def test_identity_shortcut_gradient_is_added_in_the_dgrad_epilogue(monkeypatch):
+    """BasicBlock with an identity shortcut: the linked path (ops.SkipLink: shortcut gradient added inside
+    the first convolution's dgrad) must give the bitwise-same input gradient as the unlinked path
+    (separate add), and the linked path must actually run."""
+    from zeroshotvideoclassification_amd import ops, resnet
+    torch.manual_seed(3)
+    block = resnet.BasicBlock(64, 64, resnet.Conv2Plus1D).to(DEV).train()
+    shape = (4, 64, 8, 76, 76)                 # enough voxels that the dgrad runs without split-K (else: no linking)
+    x0 = torch.randn(shape, device=DEV)
+    dy = torch.randn(shape, device=DEV)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        links = []
+        orig = ops.SkipLink.__init__
+
+        def spy(self):
+            orig(self)
+            links.append(self)
+        monkeypatch.setattr(ops.SkipLink, "__init__", spy)
+        y = block(x)
+        y.backward(dy)
+        monkeypatch.setattr(ops.SkipLink, "__init__", orig)
+        return y.detach(), x.grad, [p.grad.clone() for p in block.parameters()], links
+
+    y1, g1, p1, links = run()
+    assert len(links) == 1 and links[0].armed and links[0].dres is None      # armed, and consumed by the dgrad
+    block.zero_grad()
+    monkeypatch.setenv("ZSV_NO_SKIP_FUSION", "1")
+    y2, g2, p2, links2 = run()
+    assert links2 == []
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)

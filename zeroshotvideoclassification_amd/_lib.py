@@ -34,6 +34,8 @@ SIGNATURES = {
     "zsv_conv3d_fwd_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_int32, _P, c_size_t, _P]),
     "zsv_conv3d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_conv3d_dgrad_add_supported": (c_int32, [POINTER(ConvDesc)]),
+    "zsv_conv3d_dgrad_add": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "zsv_channel_sum_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -167,11 +167,26 @@ extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
     return wbytes + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
 }
 
+// dx = dgrad + add in one pass: stride 1 (one residue class), tap kernel, no split-K
+extern "C" int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK || d->sT != 1 || d->sH != 1 || d->sW != 1) return 0;
+    IgemmParams p;
+    if (!dgrad_class_params(p, d, 0, 0, 0) || p.K == 0 || !igemm_tap_applicable(p)) return 0;
+    size_t wbytes;
+    return dgrad_plan(d, wbytes) == 1 ? 1 : 0;
+}
+
 extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
                                 void* workspace, size_t workspace_bytes, void* stream) {
+    return zsv_conv3d_dgrad_add(d, dy, w, nullptr, dx, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, const float* w, const float* add,
+                                    float* dx, void* workspace, size_t workspace_bytes, void* stream) {
     int st = conv_check(d);
     if (st) return st;
     if (!dy || !w || !dx) return ZSV_E_NULL;
+    if (add != nullptr && !zsv_conv3d_dgrad_add_supported(d)) return ZSV_E_UNSUPPORTED;
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -197,6 +212,7 @@ extern "C" int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const f
                 if (igemm_tap_applicable(p)) {
                     p.ksplit = ks;
                     p.slab_elems = (int)out_elems;
+                    p.acc_src = add;
                     st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, wbytes, slabs,
                                    (hipStream_t)stream);
                 } else {

@@ -34,6 +34,8 @@ struct IgemmParams {
     float* stat_sum;    // != nullptr (lds_epilogue only): per (channel, column tile) partial sum and sum of
     float* stat_sq;     //   squares of the produced values, [M][tiles_n] each -- BatchNorm statistics for free
     int tiles_n;
+    const float* acc_src;   // != nullptr (dgrad, stride 1, no split-K): C = result + acc_src (same layout as C) --
+                            //   the gradient of an identity shortcut added in the epilogue (resnet.py:110)
 };
 
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
@@ -68,6 +70,7 @@ __device__ __forceinline__ void store_tiles(const IgemmParams& prm, const f32x4 
                     float v = acc[i][j][r4];
                     if (bias != nullptr) v += bias[m];
                     if (prm.relu) v = fmaxf(v, 0.f);
+                    if (prm.acc_src != nullptr) v += prm.acc_src[(cbase - C) + (size_t)m * prm.oS];
                     cbase[(size_t)m * prm.oS] = v;
                 }
             }
@@ -117,9 +120,22 @@ __device__ __forceinline__ void store_tiles_lds(const IgemmParams& prm, const f3
         const bool pvalid = p < prm.P;
         const int n = pvalid ? p / prm.cS : 0;
         float* cbase = C + (size_t)n * prm.M * prm.oS + (p - n * prm.cS);
+        // shortcut gradient to add (dgrad): the NEXT row's 16 bytes are fetched while this row is stored
+        f32x4 addn = {0.f, 0.f, 0.f, 0.f};
+        auto fetch_add = [&](int rr) {
+            const int m = m0 + r0 + rr;
+            addn = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (pvalid && m < prm.M) addn = *reinterpret_cast<const f32x4*>(prm.acc_src + (cbase - C) + (size_t)m * prm.oS);
+        };
+        const bool has_add = prm.acc_src != nullptr;
+        if (has_add && wave * RPI + rsub < rows) fetch_add(wave * RPI + rsub);
         for (int rr = wave * RPI + rsub; rr < rows; rr += 4 * RPI) {
             const int m = m0 + r0 + rr;
             f32x4 v = *reinterpret_cast<const f32x4*>(&cs[rr * PITCH + 4 * c4]);
+            if (has_add) {
+                v += addn;
+                if (rr + 4 * RPI < rows) fetch_add(rr + 4 * RPI);
+            }
             if (prm.stat_sum != nullptr) {
                 // columns beyond P hold exact zeros (their gathered operand was zero): no masking
                 float s1 = (v[0] + v[1]) + (v[2] + v[3]);

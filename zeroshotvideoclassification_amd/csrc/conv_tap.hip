@@ -403,7 +403,7 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     // consecutive, 16-B aligned floats of one clip
     prm.lds_epilogue = tap_lds_epilogue_ok(prm, C) ? 1 : 0;
     if (!prm.lds_epilogue || prm.ksplit > 1) { prm.stat_sum = nullptr; prm.stat_sq = nullptr; }
-    if (prm.ksplit > 1) C = slabs;                       // partial slabs instead of the output tensor
+    if (prm.ksplit > 1) { C = slabs; prm.acc_src = nullptr; }   // partial slabs instead of the output tensor (callers check)
     const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;

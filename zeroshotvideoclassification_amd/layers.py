@@ -29,10 +29,10 @@ class Conv3d(nn.Conv3d):
 
 
 class BatchNorm3d(nn.BatchNorm3d):
-    def forward(self, x, residual=None, relu: bool = False, stats=None):
+    def forward(self, x, residual=None, relu: bool = False, stats=None, skip_link=None):
         if x.dim() != 5:
             raise ValueError(f"expected 5D input (got {x.dim()}D input)")
-        return ops.bn_module_act(x, self, residual=residual, relu=relu, stats=stats)
+        return ops.bn_module_act(x, self, residual=residual, relu=relu, stats=stats, skip_link=skip_link)
 
 
 class ReLU(nn.ReLU):

@@ -103,13 +103,25 @@ def conv_desc(x_shape: Sequence[int], w_shape: Sequence[int], stride, padding) -
     return ConvDesc(n, cin, ti, hi, wi, cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
 
 
+class SkipLink:
+    """Joins the two gradient paths of an identity shortcut (`out += residual` with residual = the
+    block input, resnet.py:102-110).  The block's tail BatchNorm+add+ReLU backward runs first and parks
+    the shortcut gradient here instead of returning it; the backward of the block's first convolution
+    (whose input IS that residual) adds it in its dgrad epilogue -- one pass less over the block input."""
+    __slots__ = ("dres", "armed")
+
+    def __init__(self):
+        self.dres = None
+        self.armed = False        # set by the convolution's forward: its backward will collect `dres`
+
+
 # ------------------------------------------------------------------------------------------
 class _Conv3d(Function):
     """aten::conv3d fwd / dgrad / wgrad (resnet.py:23-30,40-52,63-70,170,181,184,270;
     network.py:102-117), optional bias and fused ReLU (network.py:147-162)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, skip_link=None):
         _require(x, weight, bias)
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) statistics output
         if x.dim() != 5 or weight.dim() != 5:
@@ -139,6 +151,10 @@ class _Conv3d(Function):
         ctx.desc = d
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
+        ctx.skip_link = None
+        if skip_link is not None and lib.zsv_conv3d_dgrad_add_supported(byref(d)):
+            ctx.skip_link = skip_link
+            skip_link.armed = True
         ctx.save_for_backward(x, weight, y if relu else None)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -151,7 +167,7 @@ class _Conv3d(Function):
         d = ctx.desc
         lib = _lib.load()
         if dy is None:                          # output unused downstream
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dw = db = None
         with torch.cuda.device(dy.device):
@@ -163,8 +179,11 @@ class _Conv3d(Function):
                 dx = torch.empty_like(x)
                 nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
                 ws = _workspace(nbytes, dy.device)
-                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws),
-                                                nbytes, _stream()), "zsv_conv3d_dgrad")
+                add = None
+                if ctx.skip_link is not None:            # the shortcut's gradient, parked by the block's tail
+                    add, ctx.skip_link.dres = ctx.skip_link.dres, None
+                _lib.check(lib.zsv_conv3d_dgrad_add(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
+                                                    _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
@@ -173,13 +192,18 @@ class _Conv3d(Function):
                                                 _stream()), "zsv_conv3d_wgrad")
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = channel_sum(dy)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False, want_stats=False):
     """``want_stats``: also return the epilogue's BatchNorm partial statistics (or None when this
-    geometry does not produce them) as ``(y, stats)``."""
-    y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats))
+    geometry does not produce them) as ``(y, stats)``.  An input tagged with a ``SkipLink`` (by
+    ``BasicBlock.forward``: the tensor is also the block's identity shortcut) makes this convolution's
+    backward add the shortcut gradient in its dgrad epilogue."""
+    link = x.__dict__.pop("_zsv_skip_link", None) if hasattr(x, "__dict__") else None
+    if link is not None and not (torch.is_grad_enabled() and x.requires_grad):
+        link = None
+    y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats), link)
     return (y, stats) if want_stats else y
 
 
@@ -205,7 +229,8 @@ class _BatchNormAct(Function):
     (resnet.py:110) + optional ReLU (resnet.py:49,95,111) in one pass."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, stats):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, relu, stats,
+                skip_link=None):
         _require(x, gamma, beta, running_mean, running_var, residual, stats)
         x = x.contiguous()
         n, c = int(x.shape[0]), int(x.shape[1])
@@ -243,6 +268,7 @@ class _BatchNormAct(Function):
         ctx.relu = bool(relu)
         ctx.has_res = residual is not None
         ctx.dims = (n, c, s)
+        ctx.skip_link = skip_link if (skip_link is not None and skip_link.armed and residual is not None) else None
         # with a ReLU but no residual the backward recomputes the mask from x: y need not be kept
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd, y if (relu and residual is not None) else None)
         return y
@@ -272,17 +298,21 @@ class _BatchNormAct(Function):
                                       dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
         if want_res and not ctx.relu:
             dres = dy
+        if want_res and ctx.skip_link is not None:
+            # identity shortcut: the first convolution of the block adds this in its dgrad epilogue
+            ctx.skip_link.dres = dres
+            dres = None
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
                 dbeta if ctx.needs_input_grad[2] else None, None, None, dres if want_res else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, training=True, momentum=0.1,
-                   eps=1e-5, relu=False, stats=None):
+                   eps=1e-5, relu=False, stats=None, skip_link=None):
     """``stats``: BatchNorm partial statistics of ``x`` from the producing convolution's epilogue
     (``conv3d(..., want_stats=True)``); the kernel then skips its own pass over ``x``."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
-                               float(eps), bool(relu), stats if training else None)
+                               float(eps), bool(relu), stats if training else None, skip_link)
 
 
 _NBT_PENDING = None      # list of num_batches_tracked buffers to increment when the enclosing forward ends
@@ -308,7 +338,7 @@ class batched_bn_counters:
         return False
 
 
-def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None):
+def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None, skip_link=None):
     """Apply an ``nn.BatchNorm3d``-like module's parameters through the fused kernel, with
     torch's train/eval and running-statistics semantics (momentum=None -> cumulative average
     is not used anywhere in the reference and is rejected)."""
@@ -322,7 +352,8 @@ def bn_module_act(x, bn: torch.nn.Module, residual=None, relu=False, stats=None)
             bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if (bn.track_running_stats or not use_batch_stats) else None
     rv = bn.running_var if (bn.track_running_stats or not use_batch_stats) else None
-    return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu, stats)
+    return batch_norm_act(x, bn.weight, bn.bias, rm, rv, residual, use_batch_stats, bn.momentum, bn.eps, relu, stats,
+                          skip_link)
 
 
 # ------------------------------------------------------------------------------------------

@@ -22,6 +22,8 @@ from typing import Any, Callable, List, Optional, Sequence, Tuple, Type, Union
 import torch
 from torch import Tensor, nn
 
+import os
+
 from . import ops
 from .layers import AdaptiveAvgPool3d, BatchNorm3d, Conv3d, Linear, ReLU
 
@@ -129,14 +131,23 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        out = self.conv1(x)
         tail = self.conv2[1] if len(self.conv2) == 2 else None
         fused_tail = isinstance(tail, BatchNorm3d)
+        # identity shortcut: x feeds conv1's first convolution AND the tail's `out += residual`; link the
+        # two so that the shortcut's gradient is added inside that convolution's dgrad (ops.SkipLink)
+        link = None
+        if self.downsample is None and fused_tail and torch.is_grad_enabled() and x.requires_grad \
+                and os.environ.get("ZSV_NO_SKIP_FUSION") is None:
+            link = ops.SkipLink()
+            x._zsv_skip_link = link
+        out = self.conv1(x)
+        if link is not None:
+            x.__dict__.pop("_zsv_skip_link", None)           # (not consumed: conv1 does not start with a Conv3d)
         out, stats = _call(self.conv2[0], out, fused_tail and tail.training)
         residual = x if self.downsample is None else self.downsample(x)
         if fused_tail:
             # BN + `out += residual` + ReLU (resnet.py:97,110-111) in one pass
-            return tail(out, residual=residual, relu=True, stats=stats)
+            return tail(out, residual=residual, relu=True, stats=stats, skip_link=link)
         out, _ = _run_chain(list(self.conv2)[1:], out)
         return ops.add_relu(out, residual)
 
