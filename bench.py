@@ -161,7 +161,8 @@ def main():
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
     criterion = torch.nn.MSELoss().to(dev)
-    sync = ddp.GradientSync(model) if world > 1 else None
+    # every rank builds the same name-keyed weights (seed 0): no initial broadcast needed
+    sync = ddp.GradientSync(model, broadcast_initial_state=False) if world > 1 else None
 
     x = synthetic.synthetic_clips(args.batch, FRAMES, SIZE, rank=rank).to(dev)
     _, z = synthetic.synthetic_targets(args.batch, rank=rank)
