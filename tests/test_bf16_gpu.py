@@ -207,3 +207,42 @@ def test_evaluate_protocol_in_bf16():
     assert abs(a["accuracy_top5"] - b["accuracy_top5"]) <= 12.5 + 1e-6         # at most one of 8 clips flips
     with pytest.raises(RuntimeError, match="not supported"):
         train.evaluate(model, batches, table, device=torch.device(DEV), dtype=torch.float16)
+
+
+def test_conv_bf16_random_geometries():
+    """Seeded sweep over the three bf16 convolution kernels' domains (per-tap, shared image over kw,
+    frames-x-positions tiles), strides, channel pitches and ragged tiles."""
+    rng = np.random.RandomState(77)
+    kernels = [((1, 3, 3), (0, 1, 1)), ((3, 1, 1), (1, 0, 0)), ((3, 3, 3), (1, 1, 1)), ((1, 1, 1), (0, 0, 0))]
+    for it in range(20):
+        k, p = kernels[rng.randint(len(kernels))]
+        s = tuple(int(v) for v in (rng.choice([1, 1, 2]) if k[0] > 1 or k == (1, 1, 1) else 1,
+                                   rng.choice([1, 1, 2]) if k[1] > 1 or k == (1, 1, 1) else 1,
+                                   rng.choice([1, 1, 2]) if k[2] > 1 or k == (1, 1, 1) else 1))
+        cin = int(rng.choice([32, 45, 64, 100, 144]))
+        cout = int(rng.choice([33, 64, 128, 144, 230]))
+        t, h, w = int(rng.choice([2, 4, 8, 16])), int(rng.choice([4, 7, 8, 12])), int(rng.choice([4, 8, 9, 16]))
+        n = int(rng.randint(1, 4))
+        use_res, relu = bool(rng.randint(2)), bool(rng.randint(2))
+        g = torch.Generator().manual_seed(500 + it)
+        x = bf16_round(torch.randn((n, cin, t, h, w), generator=g))
+        wgt = torch.randn((cout, cin) + k, generator=g) / np.sqrt(cin * np.prod(k))
+        scale = torch.rand(cout, generator=g) + 0.5
+        shift = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv3d(x.double(), bf16_round(wgt * scale.view(-1, 1, 1, 1, 1)).double(), stride=s, padding=p)
+        ref = ref + shift.double().view(1, -1, 1, 1, 1)
+        res = None
+        if use_res:
+            res = bf16_round(torch.randn(ref.shape, generator=g))
+            ref = ref + res.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        d = ops.conv_desc(x.shape, wgt.shape, s, p)
+        blob = inference.pack_conv(d, wgt.to(DEV), scale.to(DEV), shift.to(DEV))
+        y = inference.conv_bf16(d, to_ndhwc(x.to(DEV), inference.channel_pitch(cin)), blob,
+                                to_ndhwc(res.to(DEV), inference.channel_pitch(cout)) if use_res else None, relu)
+        assert torch.count_nonzero(y[..., cout:]) == 0
+        got = from_ndhwc(y, cout).cpu().double()
+        err = (got - ref).abs()
+        tol = ref.abs() * 2.0 ** -8 + 1e-3
+        assert bool((err <= tol).all()), f"it={it} n={n} {cin}->{cout} thw={(t, h, w)} k={k} s={s}: max err {err.max().item():.3e}"

@@ -431,3 +431,32 @@ def test_conv3d_wgrad_dma_path(case, monkeypatch):
     assert torch.equal(a, run()), "bitwise reproducible"
     monkeypatch.setenv("ZSV_NO_WGRAD_DMA", "1")                     # the register-staged kernel on the same problem
     close(run(), wr.grad, what=f"{name} wgrad (register-staged)")
+
+
+def test_conv3d_wgrad_dma_random_geometries():
+    """Seeded sweep over the LDS-DMA weight-gradient kernel's domain (stride 1, equal extents, voxel
+    count a multiple of 16, >= 256 columns): channel / row-tile padding, clip wraps, 1..27 taps, every
+    column-tile width, the frame-minor chunk walk."""
+    rng = np.random.RandomState(2024)
+    kernels = [((1, 3, 3), (0, 1, 1)), ((3, 1, 1), (1, 0, 0)), ((3, 3, 3), (1, 1, 1)), ((1, 1, 1), (0, 0, 0)),
+               ((3, 3, 1), (1, 1, 0))]
+    done = 0
+    while done < 24:
+        k, p = kernels[rng.randint(len(kernels))]
+        cin = int(rng.choice([16, 24, 45, 64, 72, 100]))
+        cout = int(rng.choice([16, 40, 64, 100, 144, 230]))
+        t, h, w = int(rng.choice([1, 2, 4, 8])), int(rng.choice([4, 6, 8, 12])), int(rng.choice([4, 8, 10, 16]))
+        if (t * h * w) % 16 or np.prod(k) * ((cin + 15) // 16 * 16) < 256:
+            continue
+        n = int(rng.randint(1, 4))
+        g = torch.Generator().manual_seed(1000 + done)
+        x = torch.randn(n, cin, t, h, w, generator=g)
+        wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * np.prod(k))
+        wr = wt.double().requires_grad_()
+        yr = F.conv3d(x.double(), wr, padding=p)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy.double())
+        wg = wt.to(DEV).requires_grad_()
+        ops.conv3d(x.to(DEV), wg, None, 1, p).backward(dy.to(DEV))
+        close(wg.grad, wr.grad, rtol=5e-5, what=f"wgrad dma n={n} cin={cin} cout={cout} thw={(t, h, w)} k={k}")
+        done += 1
