@@ -195,6 +195,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # SURVEY 8d also asks for the forward-only and forward+backward times: measured AFTER the timed
+    # region (N = 1 only), never part of `value`
+    phases = None
+    if world == 1:
+        def timed(fn, iters=5):
+            fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return round(1e3 * (time.perf_counter() - t) / iters, 3)
+
+        def fwd_only():
+            with torch.no_grad():
+                train.embed(model, x)
+
+        def fwd_bwd():
+            optimizer.zero_grad(set_to_none=True)
+            criterion(train.embed(model, x), z).backward()
+
+        phases = {"forward_ms": timed(fwd_only), "forward_backward_ms": timed(fwd_bwd)}
+        optimizer.zero_grad(set_to_none=True)
+
     if rank == 0:
         total_clips = world * args.batch * args.steps
         value = total_clips / elapsed
@@ -229,6 +253,8 @@ def main():
                                "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
                                "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
                                "traffic": pmc_traffic(n)}
+        if phases is not None:
+            out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.network, args.cpu_steps)
         print(json.dumps(out), flush=True)
