@@ -23,8 +23,10 @@ def main():
     ap.add_argument("--batch", type=int, default=22)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (MIOpen searches its solvers)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    torch.backends.cudnn.benchmark = bool(a.benchmark)
     model = R.oracle_network(R.make_opt("r2plus1d_18"))
     model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
     model.to(dev).train()
@@ -42,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"what": "plain PyTorch (MIOpen / ATen) training step on the same GPU, R(2+1)D-18 fp32",
-                      "batch": a.batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(a.batch / dt, 1),
+                      "cudnn_benchmark": bool(a.benchmark), "batch": a.batch, "ms_per_step": round(dt * 1e3, 2), "clips_per_s": round(a.batch / dt, 1),
                       "torch": torch.__version__}))
 
 
