@@ -40,6 +40,13 @@ SHAPES = {
     "P1": (64, 128, (1, 1, 1), (2, 2, 2), (0, 0, 0), 16, 56, 56),
     "P2": (128, 256, (1, 1, 1), (2, 2, 2), (0, 0, 0), 8, 28, 28),
     "P3": (256, 512, (1, 1, 1), (2, 2, 2), (0, 0, 0), 4, 14, 14),
+    # C3D (network.py:102-117): 3x3x3, stride 1, pad 1 -- not part of --shapes all
+    "C2": (64, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 16, 56, 56),
+    "C3a": (128, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), 8, 28, 28),
+    "C3b": (256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), 8, 28, 28),
+    "C4a": (256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14),
+    "C4b": (512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14),
+    "C5": (512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, 7, 7),
 }
 
 
@@ -53,7 +60,7 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda")
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    names = list(SHAPES) if args.shapes == "all" else args.shapes.split(",")
+    names = [n for n in SHAPES if not n.startswith("C")] if args.shapes == "all" else args.shapes.split(",")
     tot = {}
     for name in names:
         cin, cout, k, s, p, t, h, w = SHAPES[name]
