@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
         for (int s_ = 0; s_ < NS; ++s_) {
             if (s_ + 1 < NS) fetch(s_ + 1, (s_ + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);          // the MFMA burst outranks the other waves' staging / address work (+0.5 %)
 #pragma unroll
             for (int kk = 0; kk < FK; ++kk)
 #pragma unroll
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ & 1][kk][i], b[s_ & 1][kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();

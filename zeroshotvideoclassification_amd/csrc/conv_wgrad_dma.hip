@@ -259,11 +259,13 @@ __global__ __launch_bounds__(256, (TM * TN > 27 ? 2 : 3)) void conv_wgrad_dma_ke
             else if (i + 1 < TM) lds_wait1<1>(af[i % 3]);
             else lds_wait1<0>(af[i % 3]);
             __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i % 3][s], bf[j][s], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         }
