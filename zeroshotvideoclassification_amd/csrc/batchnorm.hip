@@ -171,7 +171,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const size_t base = (size_t)row * S;
     const int s0 = blockIdx.y * ROW_CHUNK;
     const int s1 = min(S, s0 + ROW_CHUNK);
-    if ((S % 4) == 0) {
+    if ((S % 4) == 0 && s1 - s0 == ROW_CHUNK) {
+        // full chunk: all 4 (8 with a residual) 16-byte loads of a thread are issued before the first use
+        float4 v[4], r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(x + base + s0 + 4 * threadIdx.x + 1024 * i);
+        if (RES) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(res + base + s0 + 4 * threadIdx.x + 1024 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x = __fmaf_rn(v[i].x, sc, sh); v[i].y = __fmaf_rn(v[i].y, sc, sh);
+            v[i].z = __fmaf_rn(v[i].z, sc, sh); v[i].w = __fmaf_rn(v[i].w, sc, sh);
+            if (RES) { v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w; }
+            if (RELU) { v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f); }
+            *reinterpret_cast<float4*>(y + base + s0 + 4 * threadIdx.x + 1024 * i) = v[i];
+        }
+    } else if ((S % 4) == 0) {
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             float4 v = *reinterpret_cast<const float4*>(x + base + s);
             v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh);
@@ -296,7 +313,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const size_t base = (size_t)row * S;
     const int s0 = blockIdx.y * ROW_CHUNK;
     const int s1 = min(S, s0 + ROW_CHUNK);
-    if ((S % 4) == 0) {
+    if ((S % 4) == 0 && s1 - s0 == ROW_CHUNK) {
+        // full chunk: the 8 (12 with a saved-output mask) 16-byte loads of a thread are issued up front
+        float4 gv[4], xq[4], yq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gv[i] = *reinterpret_cast<const float4*>(dy + base + s0 + 4 * threadIdx.x + 1024 * i);
+            xq[i] = *reinterpret_cast<const float4*>(x + base + s0 + 4 * threadIdx.x + 1024 * i);
+            if (RELU == 1) yq[i] = *reinterpret_cast<const float4*>(y + base + s0 + 4 * threadIdx.x + 1024 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 g = gv[i];
+            const float4 xv = xq[i];
+            const int s = s0 + 4 * threadIdx.x + 1024 * i;
+            if (RELU == 1) {
+                const float4 yv = yq[i];
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            } else if (RELU == 2) {
+                g.x = __fmaf_rn(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = __fmaf_rn(xv.y, sc, sh) > 0.f ? g.y : 0.f;
+                g.z = __fmaf_rn(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = __fmaf_rn(xv.w, sc, sh) > 0.f ? g.w : 0.f;
+            }
+            if (DRES) *reinterpret_cast<float4*>(dres + base + s) = g;
+            float4 o;
+            o.x = a * g.x + b * xv.x + k; o.y = a * g.y + b * xv.y + k;
+            o.z = a * g.z + b * xv.z + k; o.w = a * g.w + b * xv.w + k;
+            *reinterpret_cast<float4*>(dx + base + s) = o;
+        }
+    } else if ((S % 4) == 0) {
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             float4 g = *reinterpret_cast<const float4*>(dy + base + s);
             const float4 xv = *reinterpret_cast<const float4*>(x + base + s);
