@@ -165,3 +165,16 @@ def test_synthetic_inputs_follow_the_input_contract():
     assert all(torch.equal(a[k], b[k]) for k in a)
     w = a["model.layer1.0.conv1.0.0.weight"]
     assert abs(w.std().item() / (2.0 / (144 * 9)) ** 0.5 - 1) < 0.02     # kaiming fan_out (resnet.py:228)
+
+
+def test_bench_refuses_to_run_without_the_gpu():
+    """bench.py measures the HIP path only: on a host without an MI355X it must exit loudly, not fall back."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert r.returncode != 0
+    assert "MI355X" in (r.stderr + r.stdout)
+    assert "clips/s" not in r.stdout
