@@ -63,6 +63,17 @@ int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y);
 int zsv_conv3d_fwd_stats(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
                          float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Inference forward with the block tail fused: y = relu?(conv3d(x, w) + bias + residual) -- with the
+ * eval-mode BatchNorm folded into (w, bias) this is Conv3d -> BatchNorm3d -> `out += residual` -> ReLU
+ * (resnet.py:97,110-111) in one pass.  Only where zsv_conv3d_fwd_add_supported(d) != 0 (tap kernel, no
+ * split-K); `residual` has y's shape.  zsv_conv3d_fwd_full is the common form of the three entry points. */
+int32_t zsv_conv3d_fwd_add_supported(const zsv_conv_desc* d);
+int zsv_conv3d_fwd_add(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                       const float* residual, float* y, int fuse_relu, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const float* residual, float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles,
+                        void* workspace, size_t workspace_bytes, void* stream);
 int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
                    float* y, int fuse_relu, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv3d_input_grad(dy, w): what autograd runs for every conv but the first.  Strided

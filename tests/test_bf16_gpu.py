@@ -246,3 +246,22 @@ def test_conv_bf16_random_geometries():
         err = (got - ref).abs()
         tol = ref.abs() * 2.0 ** -8 + 1e-3
         assert bool((err <= tol).all()), f"it={it} n={n} {cin}->{cout} thw={(t, h, w)} k={k} s={s}: max err {err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("name", ["r2plus1d_18", "r3d_18"])
+def test_fp32_engine_with_folded_batchnorm_matches_module_forward(name):
+    """Fp32Engine (BatchNorm folded into the weights, ReLU / residual in the conv epilogue) against the
+    module's own eval forward: fp32 both, so only the folding's rounding differs (<= 1e-5 of the scale;
+    north_star's bar is 1e-3)."""
+    model = _model(name, seed=11)
+    x = synthetic.synthetic_clips(3, 8, 64, seed=5).to(DEV)
+    with torch.no_grad():
+        ref, _ = model(x)
+    emb, second = inference.Fp32Engine(model)(x)
+    assert second is None and emb.dtype == torch.float32 and emb.shape == ref.shape
+    assert (emb - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-7
+    table = synthetic.class_table(51)
+    labels, z = synthetic.synthetic_targets(3, 51)
+    a = train.evaluate(model, [(x.cpu(), labels, z)], table, device=torch.device(DEV), splits=0)
+    b = train.evaluate(model, [(x.cpu(), labels, z)], table, device=torch.device(DEV), splits=0, dtype=torch.float32)
+    assert a["accuracy"] == b["accuracy"] and a["accuracy_top5"] == b["accuracy_top5"]

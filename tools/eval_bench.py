@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=22)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--batches", type=int, default=6)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp32-folded", "bf16"])
     args = ap.parse_args()
     dev = torch.device("cuda")
     model = network.get_network(SimpleNamespace(network="r2plus1d_18", fixconvs=False, nopretrained=False))
@@ -38,7 +38,7 @@ def main():
             x = synthetic.synthetic_clips(args.batch, args.frames, 112, seed=7000 + i).to(dev)
             labels, z = synthetic.synthetic_targets(args.batch, ncls, seed=1000 + ncls, rank=i)
             batches.append((x, labels, z))
-        dt_ = torch.bfloat16 if args.dtype == "bf16" else None
+        dt_ = {"bf16": torch.bfloat16, "fp32-folded": torch.float32}.get(args.dtype)
         train.evaluate(model, batches[:1], table, device=dev, splits=0, dtype=dt_)          # warm-up
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -32,6 +32,9 @@ SIGNATURES = {
     "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "zsv_conv3d_fwd_stat_tiles": (c_int32, [POINTER(ConvDesc), _P]),
     "zsv_conv3d_fwd_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_int32, _P, c_size_t, _P]),
+    "zsv_conv3d_fwd_add_supported": (c_int32, [POINTER(ConvDesc)]),
+    "zsv_conv3d_fwd_add": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "zsv_conv3d_fwd_full": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_int32, _P, c_size_t, _P]),
     "zsv_conv3d_dgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_dgrad_add_supported": (c_int32, [POINTER(ConvDesc)]),

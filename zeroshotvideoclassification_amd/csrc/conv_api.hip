@@ -106,14 +106,37 @@ extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const floa
     return zsv_conv3d_fwd_stats(d, x, w, bias, y, fuse_relu, nullptr, 0, workspace, workspace_bytes, stream);
 }
 
+// y = act(conv + bias + residual) in one pass: tap kernel without split-K
+extern "C" int32_t zsv_conv3d_fwd_add_supported(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    IgemmParams p;
+    fwd_params(p, d, 0);
+    return (igemm_tap_applicable(p) && igemm_tap_ksplit(p) == 1) ? 1 : 0;
+}
+
 extern "C" int zsv_conv3d_fwd_stats(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
                                     float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+    return zsv_conv3d_fwd_full(d, x, w, bias, nullptr, y, fuse_relu, bn_partials, stat_tiles, workspace, workspace_bytes,
+                               stream);
+}
+
+extern "C" int zsv_conv3d_fwd_add(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                                  const float* residual, float* y, int fuse_relu, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return zsv_conv3d_fwd_full(d, x, w, bias, residual, y, fuse_relu, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                                   const float* residual, float* y, int fuse_relu, float* bn_partials,
+                                   int32_t stat_tiles, void* workspace, size_t workspace_bytes, void* stream) {
     int st = conv_check(d);
     if (st) return st;
     if (!x || !w || !y) return ZSV_E_NULL;
+    if (residual != nullptr && (bn_partials != nullptr || !zsv_conv3d_fwd_add_supported(d))) return ZSV_E_UNSUPPORTED;
     IgemmParams p;
     fwd_params(p, d, fuse_relu);
+    p.acc_src = residual;
     if (bn_partials) {
         // the partials describe the raw convolution output: only without bias / ReLU, and only on the
         // kernel path zsv_conv3d_fwd_stat_tiles() promised

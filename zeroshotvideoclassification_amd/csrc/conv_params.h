@@ -34,8 +34,9 @@ struct IgemmParams {
     float* stat_sum;    // != nullptr (lds_epilogue only): per (channel, column tile) partial sum and sum of
     float* stat_sq;     //   squares of the produced values, [M][tiles_n] each -- BatchNorm statistics for free
     int tiles_n;
-    const float* acc_src;   // != nullptr (dgrad, stride 1, no split-K): C = result + acc_src (same layout as C) --
-                            //   the gradient of an identity shortcut added in the epilogue (resnet.py:110)
+    const float* acc_src;   // != nullptr (no split-K): C = act(result + acc_src + bias), acc_src laid out like C -- the
+                            //   gradient of an identity shortcut in a dgrad, or `out += residual` of an inference forward
+                            //   (resnet.py:110), added in the epilogue
 };
 
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
@@ -68,9 +69,9 @@ __device__ __forceinline__ void store_tiles(const IgemmParams& prm, const f32x4 
                 const int m = m_base + 16 * i + 4 * frag_row + r4;
                 if (m < prm.M) {
                     float v = acc[i][j][r4];
+                    if (prm.acc_src != nullptr) v += prm.acc_src[(cbase - C) + (size_t)m * prm.oS];
                     if (bias != nullptr) v += bias[m];
                     if (prm.relu) v = fmaxf(v, 0.f);
-                    if (prm.acc_src != nullptr) v += prm.acc_src[(cbase - C) + (size_t)m * prm.oS];
                     cbase[(size_t)m * prm.oS] = v;
                 }
             }

@@ -149,7 +149,7 @@ class _ConvOp:
         return conv_bf16(d, x, self._blob, residual, self.relu)
 
 
-def _conv_bn_relu_chain(mods: List[nn.Module]) -> List[_ConvOp]:
+def _conv_bn_relu_chain(mods: List[nn.Module], keep_modules: bool = False) -> List[_ConvOp]:
     """[Conv3d, BN?, ReLU?, Conv3d, ...] (nested Sequentials flattened) -> folded ops."""
     flat: List[nn.Module] = []
 
@@ -176,7 +176,10 @@ def _conv_bn_relu_chain(mods: List[nn.Module]) -> List[_ConvOp]:
         if i < len(flat) and isinstance(flat[i], nn.ReLU):
             relu = True
             i += 1
-        out.append(_ConvOp(conv, bn, relu))
+        op = _ConvOp(conv, bn, relu)
+        if keep_modules:
+            op._conv, op._bn = conv, bn
+        out.append(op)
     return out
 
 
@@ -240,14 +243,100 @@ class Bf16Engine:
         return F.normalize(emb, dim=-1), None                          # network.py:596,600
 
 
-def engine_for(model: nn.Module) -> Bf16Engine:
-    """The model's bf16 engine, rebuilt only when a trunk parameter or BatchNorm buffer has been written
+class _ConvOpF32:
+    """One folded fp32 convolution: w * scale and shift are formed once; ReLU and the block's residual add
+    run in the convolution's epilogue (``zsv_conv3d_fwd_add``)."""
+
+    def __init__(self, conv: nn.Conv3d, bn: Optional[nn.BatchNorm3d], relu: bool):
+        scale, shift = fold_bn(bn, conv)
+        w = conv.weight.detach().float()
+        self.weight = (w * scale.view(-1, 1, 1, 1, 1)).contiguous() if scale is not None else w.contiguous()
+        self.bias = shift
+        self.stride, self.padding, self.relu = tuple(conv.stride), tuple(conv.padding), relu
+        self.cout = self.weight.shape[0]
+
+    def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        d = ops.conv_desc(x.shape, self.weight.shape, self.stride, self.padding)
+        lib = _lib.load()
+        y = torch.empty((d.N, d.Cout, d.To, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        nbytes = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+        ws = ops._workspace(nbytes, x.device)
+        fused = residual is None or bool(lib.zsv_conv3d_fwd_add_supported(byref(d)))
+        _lib.check(lib.zsv_conv3d_fwd_add(byref(d), x.data_ptr(), self.weight.data_ptr(), ops._ptr(self.bias),
+                                          ops._ptr(residual if fused else None), y.data_ptr(),
+                                          1 if (self.relu and fused) else 0, ops._ptr(ws), nbytes, ops._stream()),
+                   "zsv_conv3d_fwd_add")
+        if not fused:                                   # split-K geometry: separate add (+ ReLU)
+            y = ops.add_relu(y, residual) if self.relu else y + residual
+        return y
+
+
+class Fp32Engine:
+    """Eval-mode ``Model.forward`` in fp32 with every BatchNorm folded into its convolution:
+    same contract and structure as ``Bf16Engine``, fp32 NCDHW activations, no BatchNorm kernels."""
+
+    def __init__(self, model: nn.Module):
+        from . import network, resnet
+        model = getattr(model, "module", model)
+        if not isinstance(model, network.Model) or not isinstance(model.model, resnet.VideoResNet):
+            raise RuntimeError("Fp32Engine supports network.Model over a resnet.VideoResNet trunk")
+        if next(model.parameters()).device.type != "cuda":
+            raise RuntimeError("Fp32Engine: the model must live on the MI355X HIP device (there is no CPU fallback)")
+        self.model = model
+        chain = lambda mods: [_ConvOpF32(o._conv, o._bn, o.relu) for o in _conv_bn_relu_chain(mods, keep_modules=True)]
+        trunk = model.model
+        self.stem = chain(list(trunk.stem))
+        self.blocks = []
+        for layer in (trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4):
+            for block in layer:
+                if not isinstance(block, resnet.BasicBlock):
+                    raise RuntimeError("Fp32Engine: only BasicBlock trunks (the reference's *_18 models) are supported")
+                conv1, conv2 = chain(list(block.conv1)), chain(list(block.conv2))
+                conv2[-1].relu = True                   # out += residual; relu (resnet.py:110-111)
+                down = chain(list(block.downsample)) if block.downsample is not None else None
+                self.blocks.append((conv1, conv2, down))
+
+    @torch.no_grad()
+    def trunk(self, clips: torch.Tensor) -> torch.Tensor:
+        ops._require(clips)
+        x = clips.contiguous()
+        for op in self.stem:
+            x = op(x)
+        for conv1, conv2, down in self.blocks:
+            residual = x
+            if down is not None:
+                for op in down:
+                    residual = op(residual)
+            y = x
+            for op in conv1:
+                y = op(y)
+            for op in conv2[:-1]:
+                y = op(y)
+            x = conv2[-1](y, residual=residual)
+        return ops.mean_pool(x)
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        bs, nc = x.shape[:2]
+        pooled = self.trunk(x.reshape(bs * nc, *x.shape[2:]))
+        return F.normalize(self.model.output2emb_proj(pooled), dim=-1), None
+
+
+def engine_for(model: nn.Module, dtype: torch.dtype = torch.bfloat16):
+    """The model's inference engine for ``dtype`` (bf16: ``Bf16Engine``, fp32: ``Fp32Engine``), rebuilt only when a trunk parameter or BatchNorm buffer has been written
     since it was built (tensor version counters), e.g. once per epoch for the three test sets of
     main.py:352-358."""
     own = getattr(model, "module", model)
     key = tuple(t._version for t in list(own.model.parameters()) + list(own.model.buffers()))
-    cached = getattr(own, "_zsv_bf16_engine", None)
+    cache = own.__dict__.setdefault("_zsv_engines", {})
+    cached = cache.get(dtype)
     if cached is None or cached[0] != key:
-        cached = (key, Bf16Engine(own))
-        own._zsv_bf16_engine = cached
+        if dtype == torch.bfloat16:
+            engine = Bf16Engine(own)
+        elif dtype == torch.float32:
+            engine = Fp32Engine(own)
+        else:
+            raise RuntimeError(f"no inference engine for {dtype} (fp32 or bf16)")
+        cached = (key, engine)
+        cache[dtype] = cached
     return cached[1]

@@ -98,15 +98,16 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
     """main.py:224-313 for one test set.  ``batches`` yields ``(X, labels, Z, ...)``; samples with
     label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248.
     ``dtype=torch.bfloat16`` runs the forward on the bf16 engine (``inference.Bf16Engine``, the
-    reduced-precision eval of BASELINE config 5 / the reference's autocast, main.py:172); default fp32."""
+    reduced-precision eval of BASELINE config 5 / the reference's autocast, main.py:172), ``torch.float32``
+    on the folded fp32 engine (``inference.Fp32Engine``); default (None): the module's own fp32 forward."""
     was_training = model.training
     model.eval()
     device = device or next(model.parameters()).device
     forward = model
-    if dtype == torch.bfloat16:
+    if dtype in (torch.bfloat16, torch.float32):
         from .inference import engine_for
-        forward = engine_for(model)
-    elif dtype not in (None, torch.float32):
+        forward = engine_for(model, dtype)                 # BatchNorm folded; fp32 or bf16 activations
+    elif dtype is not None:
         raise RuntimeError(f"evaluate: dtype {dtype} is not supported (fp32 or bf16)")
     preds, trues, labels = [], [], []
     for batch in batches:
