@@ -265,3 +265,17 @@ def test_fp32_engine_with_folded_batchnorm_matches_module_forward(name):
     a = train.evaluate(model, [(x.cpu(), labels, z)], table, device=torch.device(DEV), splits=0)
     b = train.evaluate(model, [(x.cpu(), labels, z)], table, device=torch.device(DEV), splits=0, dtype=torch.float32)
     assert a["accuracy"] == b["accuracy"] and a["accuracy_top5"] == b["accuracy_top5"]
+
+
+@pytest.mark.parametrize("n,t,s", [(1, 24, 96), (3, 8, 80), (2, 16, 128)])
+def test_engines_on_other_clip_sizes(n, t, s):
+    """Frame counts / resolutions other than the benchmark's: tile-eligibility rules (frames-x-positions
+    tiles need T % 8 == 0 and HW % 32 == 0, the shared image stride 1, ...) must fall back, not break."""
+    model = _model("r2plus1d_18", seed=2)
+    x = synthetic.synthetic_clips(n, t, s, seed=t + s).to(DEV)
+    with torch.no_grad():
+        ref, _ = model(x)
+    b, _ = inference.Bf16Engine(model)(x)
+    f, _ = inference.Fp32Engine(model)(x)
+    assert (b * ref).sum(dim=1).min().item() >= 0.999 and (b - ref).abs().max().item() <= 2e-2
+    assert (f - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-7
