@@ -359,3 +359,39 @@ def test_identity_shortcut_gradient_is_added_in_the_dgrad_epilogue(monkeypatch):
     assert torch.equal(y1, y2) and torch.equal(g1, g2)
     for a, b in zip(p1, p2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,t,h,w", [(2, 8, 72, 88), (3, 10, 50, 50)])
+def test_odd_clip_sizes_forward_backward_match_the_oracle(n, t, h, w):
+    """Clip sizes whose feature maps are odd / not multiples of the kernels' vector widths (voxel counts
+    not divisible by 4 or 16: the register-staged wgrad, scalar epilogues, ragged tiles): train-mode
+    forward, loss and every parameter gradient against the CPU oracle (fp32) on the same weights."""
+    from oracle import restatement as R
+    opt = make_opt("r2plus1d_18")
+    model = network.get_network(opt)
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=4, bn_jitter=True)
+    model.load_state_dict(weights)
+    oracle = R.oracle_network(opt)
+    oracle.load_state_dict(weights)
+    g = torch.Generator().manual_seed(h * w + t)
+    x = (torch.randint(0, 256, (n, 1, 3, t, h, w), generator=g).float() / 255.0 - 1.0) / 2.0
+    _, z = synthetic.synthetic_targets(n)
+    oracle.train()
+    y_ref = R.embed(oracle, x)
+    loss_ref = F.mse_loss(y_ref, z)
+    loss_ref.backward()
+    model.to(DEV).train()
+    y = train.embed(model, x.to(DEV))
+    loss = F.mse_loss(y, z.to(DEV))
+    loss.backward()
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < TIGHT
+    assert abs(loss.item() / loss_ref.item() - 1) < TIGHT
+    ref_grads = {k: p.grad for k, p in oracle.named_parameters() if p.grad is not None}
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_grads)
+    worst = 0.0
+    for k, gr in ref_grads.items():
+        a, b = got[k].detach().cpu().double().flatten(), gr.double().flatten()
+        worst = max(worst, ((a - b).norm() / (b.norm() + 1e-30)).item())
+    # fp32 GPU vs fp32 CPU, different summation orders through ~40 layers of BatchNorm backward
+    assert worst < 5e-2, f"worst per-parameter gradient rel-L2 {worst:.3e}"
