@@ -460,3 +460,40 @@ def test_conv3d_wgrad_dma_random_geometries():
         ops.conv3d(x.to(DEV), wg, None, 1, p).backward(dy.to(DEV))
         close(wg.grad, wr.grad, rtol=5e-5, what=f"wgrad dma n={n} cin={cin} cout={cout} thw={(t, h, w)} k={k}")
         done += 1
+
+
+@pytest.mark.parametrize("n,cin,cout,thw", [(4, 32, 16, (8, 96, 96)), (2, 100, 24, (4, 96, 180)), (6, 64, 48, (16, 56, 56))],
+                         ids=["one_row_tile", "two_row_tiles_padded_channels", "s1_like"])
+def test_conv3d_dgrad_winograd_path(n, cin, cout, thw, monkeypatch):
+    """Input gradient of the 1x3x3 stride-1 convolutions through the Winograd F(2,3)-along-W kernel (large
+    voxel counts only: it has no split-K form) against torch CPU fp64 and against the direct kernel; with
+    and without the fused shortcut-gradient add."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    t, h, w = thw
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    wt = torch.randn(cout, cin, 1, 3, 3, generator=g) / np.sqrt(cin * 9)
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    add = torch.randn(n, cin, t, h, w, generator=g)
+    ref = torch.nn.grad.conv3d_input((n, cin, t, h, w), wt.double(), dy.double(), stride=1, padding=(0, 1, 1))
+    lib = _lib.load()
+    d = ops.conv_desc((n, cin, t, h, w), wt.shape, 1, (0, 1, 1))
+
+    def run(with_add):
+        dx = torch.empty((n, cin, t, h, w), device=DEV)
+        nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        a = add.to(DEV) if with_add else None
+        _lib.check(lib.zsv_conv3d_dgrad_add(ctypes.byref(d), dy.to(DEV).data_ptr(), wt.to(DEV).data_ptr(),
+                                            a.data_ptr() if a is not None else None, dx.data_ptr(), ws.data_ptr(), nbytes,
+                                            None), "dgrad")
+        torch.cuda.synchronize()
+        return dx
+
+    close(run(False), ref, what="winograd dgrad")
+    close(run(True), ref + add.double(), what="winograd dgrad + add")
+    fast = run(False)
+    monkeypatch.setenv("ZSV_NO_WINO", "1")
+    direct = run(False)
+    close(fast, direct.double(), rtol=5e-6, what="winograd vs direct kernel")
+    assert not torch.equal(fast, direct), "the two paths should not be the same kernel"

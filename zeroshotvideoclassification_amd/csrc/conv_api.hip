@@ -184,6 +184,7 @@ static int dgrad_plan(const zsv_conv_desc* d, size_t& wbytes) {
 
 extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (wino_dgrad_applicable(d)) return wino_dgrad_workspace_bytes(d);
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const size_t out_elems = (size_t)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -193,6 +194,7 @@ extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
 // dx = dgrad + add in one pass: stride 1 (one residue class), tap kernel, no split-K
 extern "C" int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK || d->sT != 1 || d->sH != 1 || d->sW != 1) return 0;
+    if (wino_dgrad_applicable(d)) return 1;
     IgemmParams p;
     if (!dgrad_class_params(p, d, 0, 0, 0) || p.K == 0 || !igemm_tap_applicable(p)) return 0;
     size_t wbytes;
@@ -210,6 +212,7 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
     if (st) return st;
     if (!dy || !w || !dx) return ZSV_E_NULL;
     if (add != nullptr && !zsv_conv3d_dgrad_add_supported(d)) return ZSV_E_UNSUPPORTED;
+    if (wino_dgrad_applicable(d)) return wino_dgrad(d, dy, w, add, dx, workspace, workspace_bytes, (hipStream_t)stream);
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;

@@ -183,6 +183,11 @@ int conv_check(const zsv_conv_desc* d);
 size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                   size_t workspace_bytes, hipStream_t stream);
+// Winograd F(2,3)-along-W input gradient of the 1x3x3 stride-1 convolutions (conv_wino.hip)
+bool wino_dgrad_applicable(const zsv_conv_desc* d);
+size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d);
+int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
+               size_t workspace_bytes, hipStream_t stream);
 // LDS-DMA weight gradient of stride-1 "same" convolutions (conv_wgrad_dma.hip): writes the per-slice
 // slabs [slice][Cout][taps*Cpad] at the start of `workspace`
 bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* dy);

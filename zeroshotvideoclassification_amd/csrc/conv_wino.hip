@@ -1,0 +1,296 @@
+// conv_wino.hip -- 1x3x3 stride-1 "same" convolution with the kw taps in Winograd F(2,3) form (fp32).
+//
+//   out[m][t,h,w] = sum_{c,kh,kw} G[m][c][kh][kw] * in[c][t, h+kh-1, w+kw-1]
+// (used for the input gradient of Conv2Plus1D's spatial convolution, resnet.py:40-45: in = dy, m = input
+// channel, G = the weights with both spatial axes flipped).  Along W two adjacent outputs share their
+// inputs: with d0..d3 = in[w-1..w+2] of one (c, kh) row and g0..g2 the three kw weights,
+//     V0 = d0-d2   V1 = d1+d2   V2 = d2-d1   V3 = d1-d3
+//     U0 = g0      U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2
+//     y(w) = M0+M1+M2,   y(w+1) = M1-M2-M3,   Mi = sum_{c,kh} Ui * Vi
+// i.e. 4 multiplies per output pair instead of 6: 1.5x fewer MFMAs, still fp32 in / fp32 accumulate
+// (the only rounding added is the 3-term sums of U, ~1e-7 relative).
+//
+// Implicit GEMM per point i: rows = 64 output channels (4 blocks), columns = 128 voxel PAIRS per
+// workgroup (4 waves x 2 blocks of 16 pairs = 256 consecutive voxels; W is even, so a pair never
+// straddles a row), K = (16-channel block, kh).  Per chunk the four U panels [16][64] and ONE raw input
+// image [16][256 + 2 halo] are staged by LDS-DMA; the V transform happens on the B fragment in
+// registers (two ds_read_b64 + 4 VALU give the fragments of all four points), so the input is gathered
+// once per (block, kh) instead of once per tap.  Row ends (w-1 < 0, w+2 >= W) zero d0 / d3 per lane.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "conv_params.h"
+#include "zsv_common.h"
+#include "zsv_hip.h"
+
+namespace zsv {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinoParams {
+    int M, Mp;              // output channels, padded to 64
+    int C, nblk;            // reduction channels, 16-channel blocks
+    int S, HW, W, H;        // voxels per clip / frame, row length, rows
+    int P;                  // N * S
+    unsigned in_bytes;
+    int tiles_m;
+    const float* add;       // != nullptr: out += add (identity-shortcut gradient, as zsv_conv3d_dgrad_add)
+};
+
+// Up[((cb*3 + kh)*4 + pt)*16 + c%16][Mp] from G[m][c][kh][kw] = W[m*sm + c*sc + (flip ? 8 - (3*kh+kw) : 3*kh+kw)]
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
+                                                        int C, int nblk, long sm, long sc, int flip, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i % Mp);
+        long r = i / Mp;
+        const int c16 = (int)(r % 16);
+        r /= 16;
+        const int pt = (int)(r % 4);
+        r /= 4;
+        const int kh = (int)(r % 3);
+        const int cb = (int)(r / 3);
+        const int c = cb * 16 + c16;
+        float v = 0.f;
+        if (m < M && c < C) {
+            const float* g = W + (size_t)m * sm + (size_t)c * sc;
+            const int k0 = flip ? 8 - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? 8 - (3 * kh + 1) : 3 * kh + 1,
+                      k2 = flip ? 8 - (3 * kh + 2) : 3 * kh + 2;
+            const float g0 = g[k0], g1 = g[k1], g2 = g[k2];
+            v = pt == 0 ? g0 : pt == 1 ? 0.5f * ((g0 + g2) + g1) : pt == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
+        }
+        Up[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const float* __restrict__ Up,
+                                                           const float* __restrict__ IN, float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 64, BN = 256, BK = 16;
+    constexpr int LDA = 80;                 // 64 + 16: k-major rows, ds_read_b32 conflict-free (pitch = 16 mod 32)
+    constexpr int LDB = 288;                // 258 used; = 32 mod 64 so the two k rows of a ds_read_b64 pass split the banks
+    constexpr int A_FLOATS = 4 * BK * LDA, B_FLOATS = BK * LDB;
+    constexpr int HALO_AT = A_FLOATS + B_FLOATS;      // 64 floats of scratch: where the halo DMA lands
+    constexpr int STAGE = HALO_AT + 64;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    extern __shared__ __attribute__((aligned(16))) float pool[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int m0 = (tile % prm.tiles_m) * BM;
+    const int n0 = (tile / prm.tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
+    const int ch_bytes = 4 * prm.S;
+
+    // ---- this lane's voxel of the raw image: column 1 + 64*wave + lane --------------------------
+    auto decode = [&](int p, int& base_bytes, unsigned& hmask) {
+        base_bytes = 0;
+        hmask = 0;
+        if (p >= 0 && p < prm.P) {
+            const int n = p / prm.S;
+            int r = p - n * prm.S;
+            const int t = r / prm.HW;
+            r -= t * prm.HW;
+            const int h = r / prm.W;
+            base_bytes = 4 * (n * prm.C * prm.S + (p - n * prm.S));
+            for (int kh = 0; kh < 3; ++kh) hmask |= (unsigned)((unsigned)(h + kh - 1) < (unsigned)prm.H) << kh;
+        }
+    };
+    int base_bytes;
+    unsigned hmask;
+    decode(n0 + 64 * wave + lane, base_bytes, hmask);
+    // halo columns 0 and 257 (voxels n0-1, n0+256): wave 0, lanes 0..31 = (k row, side)
+    int halo_base = 0;
+    unsigned halo_mask = 0;
+    if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
+
+    // U panels: linear image of [4][16][LDA]; 16-byte slots
+    constexpr int ASLOTS = A_FLOATS / 4;             // 1280
+    constexpr int APASS = ASLOTS / 256;              // 5
+    const float* a_src[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int slot = 64 * (wave + 4 * j) + lane;
+        const int row = slot / (LDA / 4), c4 = slot % (LDA / 4);         // row = pt*16 + k
+        a_src[j] = Up + (size_t)row * prm.Mp + m0 + (c4 < BM / 4 ? 4 * c4 : 0);
+    }
+    const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
+
+    const int nchunks = prm.nblk * 3;
+    int ld_cb = 0, ld_kh = 0;
+    auto issue = [&](int chunk, int buf) {
+        float* as = pool + buf * STAGE;
+        float* bs = as + A_FLOATS;
+        const int toff = 4 * (ld_kh - 1) * prm.W;
+        const unsigned ok = (hmask >> ld_kh) & 1u;
+        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);
+        const int ci0 = ld_cb * 16;
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            const int ci = ci0 + k;
+            const unsigned v = ci < prm.C ? voff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + 1 + 64 * wave), 4, (int)v,
+                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+        }
+        if (wave == 0) {
+            // one instruction: lanes 0..31 -> (k = lane/2, side = lane&1); the destination must be lane-linear,
+            // so the 32 halo values land in a scratch row and are moved by 32 lanes after the wait
+            const int k = lane >> 1;
+            const int ci = ci0 + k;
+            const unsigned hok = (halo_mask >> ld_kh) & 1u;
+            unsigned hv = (unsigned)(halo_base + toff) | (hok - 1u);
+            if (lane >= 32 || ci >= prm.C) hv = OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(as + HALO_AT), 4, (int)(hv + (hv == OOB ? 0u : (unsigned)(ci * ch_bytes))), 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
+        if (++ld_kh == 3) { ld_kh = 0; ++ld_cb; }
+    };
+    // after the DMAs of a stage have landed: scatter the 32 halo values into columns 0 / 257 of their rows
+    auto place_halo = [&](int buf) {
+        if (wave == 0 && lane < 32) {
+            float* bs = pool + buf * STAGE + A_FLOATS;
+            const float v = pool[buf * STAGE + HALO_AT + lane];
+            bs[(lane >> 1) * LDB + ((lane & 1) ? BN + 1 : 0)] = v;
+        }
+    };
+
+    f32x4 acc[4][4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    // row-end masks of this lane's two pairs: d0 is outside if the pair starts a row, d3 if it ends one
+    bool zero_d0[2], zero_d3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int v = n0 + 64 * wave + 2 * (16 * j + r16);          // first voxel of the pair
+        const int w = v % prm.W;
+        zero_d0[j] = w == 0;
+        zero_d3[j] = w + 2 >= prm.W;
+    }
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 0 moves the halo values its own DMA fetched
+    place_halo(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        const float* as = pool + cur * STAGE;
+        const float* bs = as + A_FLOATS;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int krow = 4 * s + g;
+            float a[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
+            float v[4][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float* src = bs + krow * LDB + 64 * wave + 2 * (16 * j + r16);       // image column of d0
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(src), hi = *reinterpret_cast<const f32x2*>(src + 2);
+                const float d0 = zero_d0[j] ? 0.f : lo[0], d1 = lo[1], d2 = hi[0], d3 = zero_d3[j] ? 0.f : hi[1];
+                v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][i], v[p][j], acc[p][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ch + 1 < nchunks) place_halo(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- output transform + store: lane holds rows 4g..4g+3 of pair column r16 ---------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int v0 = n0 + 64 * wave + 2 * (16 * j + r16);
+        if (v0 >= prm.P) continue;
+        const int n = v0 / prm.S, sl = v0 - n * prm.S;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * i + 4 * g + r;
+                if (m >= prm.M) continue;
+                const float M0 = acc[0][i][j][r], M1 = acc[1][i][j][r], M2 = acc[2][i][j][r], M3 = acc[3][i][j][r];
+                f32x2 y = {(M0 + M1) + M2, (M1 - M2) - M3};
+                const size_t off = ((size_t)n * prm.M + m) * prm.S + sl;
+                if (prm.add != nullptr) y += *reinterpret_cast<const f32x2*>(prm.add + off);
+                *reinterpret_cast<f32x2*>(OUT + off) = y;
+            }
+        }
+    }
+#endif
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// dgrad of a 1x3x3 stride-1 pad-(0,1,1) convolution with enough voxel tiles to fill the chip
+bool wino_dgrad_applicable(const zsv_conv_desc* d) {
+    if (getenv("ZSV_NO_WINO")) return false;
+    if (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 0 || d->pH != 1 ||
+        d->pW != 1)
+        return false;
+    if (d->Wi % 2 != 0 || d->Cout < 16) return false;
+    const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
+    if (P % 2 != 0 || (long)d->N * d->Cout * d->Ti * d->Hi * d->Wi >= (1L << 30) || (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi >= (1L << 30))
+        return false;
+    const long tiles = ((d->Cin + 63) / 64) * ((P + 255) / 256);
+    return tiles >= 1024;                                // (no split-K form)
+}
+
+size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) {
+    const int Mp = (d->Cin + 63) / 64 * 64, nblk = (d->Cout + 15) / 16;
+    return wino_align((size_t)nblk * 3 * 4 * 16 * Mp * sizeof(float));
+}
+
+int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
+               size_t workspace_bytes, hipStream_t stream) {
+    if (!workspace || workspace_bytes < wino_dgrad_workspace_bytes(d)) return ZSV_E_WORKSPACE;
+    WinoParams p;
+    p.M = d->Cin;
+    p.Mp = (d->Cin + 63) / 64 * 64;
+    p.C = d->Cout;
+    p.nblk = (d->Cout + 15) / 16;
+    p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.H = d->Hi;
+    p.P = d->N * p.S;
+    p.in_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
+    p.tiles_m = p.Mp / 64;
+    p.add = add;
+    float* up = (float*)workspace;
+    const long total = (long)p.nblk * 3 * 4 * 16 * p.Mp;
+    long pb = (total + 255) / 256;
+    if (pb > 4096) pb = 4096;
+    // G[m = ci][c = co][kh][kw] = W[co][ci][2-kh][2-kw]: stride of m is 9, of c is Cin*9, taps flipped
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 9L,
+                       (long)d->Cin * 9, 1, total);
+    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    constexpr int LDS_BYTES = 2 * (4 * 16 * 80 + 16 * 288 + 64) * 4;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    const long tiles = (long)p.tiles_m * ((p.P + 255) / 256);
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, dy, dx);
+    return launch_status();
+}
+
+}  // namespace zsv
