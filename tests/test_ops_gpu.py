@@ -497,3 +497,54 @@ def test_conv3d_dgrad_winograd_path(n, cin, cout, thw, monkeypatch):
     direct = run(False)
     close(fast, direct.double(), rtol=5e-6, what="winograd vs direct kernel")
     assert not torch.equal(fast, direct), "the two paths should not be the same kernel"
+
+
+@pytest.mark.parametrize("n,cin,cout,thw", [(4, 16, 32, (8, 96, 96)), (2, 24, 100, (4, 96, 180)), (6, 64, 144, (16, 56, 56)),
+                                            (4, 45, 288, (8, 28, 56))],
+                         ids=["one_48_row_tile", "padded_channels_64_rows", "s1_48_row_tiles", "288_rows_ragged_k"])
+def test_conv3d_fwd_winograd_path(n, cin, cout, thw, monkeypatch):
+    """Forward of the 1x3x3 stride-1 convolutions through the Winograd F(2,3)-along-W kernel (64- and 48-row
+    tiles) against torch CPU fp64 and the direct kernel: plain, with the BatchNorm partial statistics of the
+    training forward, and with the inference epilogue (bias + residual + ReLU)."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    t, h, w = thw
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    wt = torch.randn(cout, cin, 1, 3, 3, generator=g) / np.sqrt(cin * 9)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, t, h, w, generator=g)
+    ref = F.conv3d(x.double(), wt.double(), padding=(0, 1, 1))
+    lib = _lib.load()
+    d = ops.conv_desc(x.shape, wt.shape, 1, (0, 1, 1))
+    xd, wd, bd, rd = x.to(DEV), wt.to(DEV), bias.to(DEV), res.to(DEV)
+
+    def run(mode):
+        y = torch.empty((n, cout, t, h, w), device=DEV)
+        nbytes = lib.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        stats, tiles = None, 0
+        if mode == "stats":
+            tiles = lib.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr())
+            assert tiles > 0
+            stats = torch.full((2, cout, tiles), float("nan"), device=DEV)
+        full = mode == "full"
+        _lib.check(lib.zsv_conv3d_fwd_full(ctypes.byref(d), xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if full else None,
+                                           rd.data_ptr() if full else None, y.data_ptr(), 1 if full else 0,
+                                           stats.data_ptr() if stats is not None else None, tiles, ws.data_ptr(), nbytes,
+                                           None), "fwd")
+        torch.cuda.synchronize()
+        return y, stats
+
+    fast, _ = run("plain")
+    close(fast, ref, what="winograd fwd")
+    y, stats = run("stats")
+    assert torch.equal(y, fast)
+    close(stats[0].double().sum(1), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="winograd fwd: sum y")
+    close(stats[1].double().sum(1), (ref * ref).sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="winograd fwd: sum y^2")
+    y, _ = run("full")
+    close(y, torch.relu(ref + bias.double().view(1, -1, 1, 1, 1) + res.double()), what="winograd fwd + bias + residual + relu")
+    monkeypatch.setenv("ZSV_NO_WINO_FWD", "1")
+    direct, _ = run("plain")
+    close(fast, direct.double(), rtol=5e-6, what="winograd vs direct kernel")
+    assert not torch.equal(fast, direct), "the two paths should not be the same kernel"

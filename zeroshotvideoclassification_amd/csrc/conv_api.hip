@@ -86,6 +86,7 @@ static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (wino_fwd_applicable(d)) return wino_fwd_workspace_bytes(d);
     IgemmParams p;
     fwd_params(p, d, 0);
     if (!igemm_tap_applicable(p)) return 0;
@@ -96,6 +97,7 @@ extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
 
 extern "C" int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (wino_fwd_applicable(d)) return getenv("ZSV_NO_FUSED_STATS") ? 0 : wino_fwd_stat_tiles(d);
     IgemmParams p;
     fwd_params(p, d, 0);
     return igemm_tap_stat_tiles(p, y);
@@ -109,6 +111,7 @@ extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const floa
 // y = act(conv + bias + residual) in one pass: tap kernel without split-K
 extern "C" int32_t zsv_conv3d_fwd_add_supported(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (wino_fwd_applicable(d)) return 1;
     IgemmParams p;
     fwd_params(p, d, 0);
     return (igemm_tap_applicable(p) && igemm_tap_ksplit(p) == 1) ? 1 : 0;
@@ -134,6 +137,12 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
     if (st) return st;
     if (!x || !w || !y) return ZSV_E_NULL;
     if (residual != nullptr && (bn_partials != nullptr || !zsv_conv3d_fwd_add_supported(d))) return ZSV_E_UNSUPPORTED;
+    if (wino_fwd_applicable(d)) {
+        if (bn_partials && (bias || fuse_relu || stat_tiles != wino_fwd_stat_tiles(d))) return ZSV_E_UNSUPPORTED;
+        return wino_fwd(d, x, w, bias, residual, fuse_relu ? 1 : 0, bn_partials,
+                        bn_partials ? bn_partials + (size_t)d->Cout * stat_tiles : nullptr, y, workspace, workspace_bytes,
+                        (hipStream_t)stream);
+    }
     IgemmParams p;
     fwd_params(p, d, fuse_relu);
     p.acc_src = residual;

@@ -188,6 +188,11 @@ bool wino_dgrad_applicable(const zsv_conv_desc* d);
 size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream);
+bool wino_fwd_applicable(const zsv_conv_desc* d);
+int wino_fwd_stat_tiles(const zsv_conv_desc* d);
+size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d);
+int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,
+             float* stat_sum, float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // LDS-DMA weight gradient of stride-1 "same" convolutions (conv_wgrad_dma.hip): writes the per-slice
 // slabs [slice][Cout][taps*Cpad] at the start of `workspace`
 bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* dy);

@@ -34,8 +34,12 @@ struct WinoParams {
     int S, HW, W, H;        // voxels per clip / frame, row length, rows
     int P;                  // N * S
     unsigned in_bytes;
-    int tiles_m;
-    const float* add;       // != nullptr: out += add (identity-shortcut gradient, as zsv_conv3d_dgrad_add)
+    int tiles_m, tiles_n;
+    const float* add;       // != nullptr: out = act(result + add + bias) (shortcut gradient / inference residual)
+    const float* bias;      // != nullptr: + bias[m]
+    int relu;
+    float* stat_sum;        // != nullptr: per (channel, column tile) sum and sum of squares of the raw result
+    float* stat_sq;         //   [M][tiles_n] each (BatchNorm statistics of a training forward)
 };
 
 // Up[((cb*3 + kh)*4 + pt)*16 + c%16][Mp] from G[m][c][kh][kw] = W[m*sm + c*sc + (flip ? 8 - (3*kh+kw) : 3*kh+kw)]
@@ -63,11 +67,14 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     }
 }
 
+// TM = 16-row blocks per workgroup (rows = 16*TM: 64 for the gradients, 48 for the 144- and 288-channel forwards)
+template <int TM>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const float* __restrict__ Up,
                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = 64, BN = 256, BK = 16;
-    constexpr int LDA = 80;                 // 64 + 16: k-major rows, ds_read_b32 conflict-free (pitch = 16 mod 32)
+    constexpr int BM = 16 * TM, BN = 256, BK = 16;
+    constexpr int LDA = BM % 32 == 16 ? BM : BM + 16;   // k-major rows, ds_read_b32 conflict-free (pitch = 16 mod 32)
+    static_assert(LDA % 32 == 16, "A pitch");
     constexpr int LDB = 288;                // 258 used; = 32 mod 64 so the two k rows of a ds_read_b64 pass split the banks
     constexpr int A_FLOATS = 4 * BK * LDA, B_FLOATS = BK * LDB;
     constexpr int HALO_AT = A_FLOATS + B_FLOATS;      // 64 floats of scratch: where the halo DMA lands
@@ -107,12 +114,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
 
     // U panels: linear image of [4][16][LDA]; 16-byte slots
-    constexpr int ASLOTS = A_FLOATS / 4;             // 1280
-    constexpr int APASS = ASLOTS / 256;              // 5
+    constexpr int ASLOTS = A_FLOATS / 4;
+    constexpr int APASS = (ASLOTS + 255) / 256;
     const float* a_src[APASS];
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-        const int slot = 64 * (wave + 4 * j) + lane;
+        int slot = 64 * (wave + 4 * j) + lane;
+        slot = slot < ASLOTS ? slot : ASLOTS - 1;                        // (surplus lanes repeat the last slot)
         const int row = slot / (LDA / 4), c4 = slot % (LDA / 4);         // row = pt*16 + k
         a_src[j] = Up + (size_t)row * prm.Mp + m0 + (c4 < BM / 4 ? 4 * c4 : 0);
     }
@@ -146,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         }
 #pragma unroll
         for (int j = 0; j < APASS; ++j)
-            __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
+            if (64 * (wave + 4 * j) < ASLOTS)              // wave-uniform
+                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
         if (++ld_kh == 3) { ld_kh = 0; ++ld_cb; }
     };
     // after the DMAs of a stage have landed: scatter the 32 halo values into columns 0 / 257 of their rows
@@ -158,11 +167,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         }
     };
 
-    f32x4 acc[4][4][2];
+    f32x4 acc[4][TM][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -189,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int krow = 4 * s + g;
-            float a[4][4];
+            float a[4][TM];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
+                for (int i = 0; i < TM; ++i) a[p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
             float v[4][2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][i], v[p][j], acc[p][i][j], 0, 0, 0);
@@ -219,24 +228,53 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         __syncthreads();
     }
 
-    // ---- output transform + store: lane holds rows 4g..4g+3 of pair column r16 ---------------------
+    // ---- output transform (+ statistics) (+ add, bias, ReLU) + store: lane holds rows 4g..4g+3 of pair column r16
+    const bool stats = prm.stat_sum != nullptr;
+    float* red = pool;                                   // [4 waves][BM][2] partial sums (the staging LDS is free now)
+    if (stats) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int v0 = n0 + 64 * wave + 2 * (16 * j + r16);
-        if (v0 >= prm.P) continue;
-        const int n = v0 / prm.S, sl = v0 - n * prm.S;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * i + 4 * g + r;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * i + 4 * g + r;
-                if (m >= prm.M) continue;
+            for (int j = 0; j < 2; ++j) {
+                const int v0 = n0 + 64 * wave + 2 * (16 * j + r16);
                 const float M0 = acc[0][i][j][r], M1 = acc[1][i][j][r], M2 = acc[2][i][j][r], M3 = acc[3][i][j][r];
                 f32x2 y = {(M0 + M1) + M2, (M1 - M2) - M3};
-                const size_t off = ((size_t)n * prm.M + m) * prm.S + sl;
-                if (prm.add != nullptr) y += *reinterpret_cast<const f32x2*>(prm.add + off);
-                *reinterpret_cast<f32x2*>(OUT + off) = y;
+                if (v0 < prm.P && m < prm.M) {
+                    s1 += y[0] + y[1];
+                    s2 += y[0] * y[0] + y[1] * y[1];
+                    const int n = v0 / prm.S, sl = v0 - n * prm.S;
+                    const size_t off = ((size_t)n * prm.M + m) * prm.S + sl;
+                    if (prm.add != nullptr) y += *reinterpret_cast<const f32x2*>(prm.add + off);
+                    if (prm.bias != nullptr) y += prm.bias[m];
+                    if (prm.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); }
+                    *reinterpret_cast<f32x2*>(OUT + off) = y;
+                }
             }
+            if (stats) {                                  // 16 lanes (r16) share row m
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (r16 == 0) {
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2] = s1;
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < prm.M) {               // the 4 waves' partials, in wave order
+            const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
+            const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
+            const int tn = n0 / BN;
+            prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + tn] = t1;
+            prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + tn] = t2;
         }
     }
 #endif
@@ -245,52 +283,86 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 // ---- host side -----------------------------------------------------------------------------------
 static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// dgrad of a 1x3x3 stride-1 pad-(0,1,1) convolution with enough voxel tiles to fill the chip
-bool wino_dgrad_applicable(const zsv_conv_desc* d) {
+// rows per workgroup for M produced channels: 64, or 48 when that pads less (144 = 3 x 48, 288 = 6 x 48)
+static int wino_tm(int M) {
+    const int p64 = (M + 63) / 64 * 64, p48 = (M + 47) / 48 * 48;
+    return p48 < p64 ? 3 : 4;
+}
+
+static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (getenv("ZSV_NO_WINO")) return false;
     if (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 0 || d->pH != 1 ||
         d->pW != 1)
         return false;
-    if (d->Wi % 2 != 0 || d->Cout < 16) return false;
+    if (d->Wi % 2 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
-    if (P % 2 != 0 || (long)d->N * d->Cout * d->Ti * d->Hi * d->Wi >= (1L << 30) || (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi >= (1L << 30))
-        return false;
-    const long tiles = ((d->Cin + 63) / 64) * ((P + 255) / 256);
+    if (P % 2 != 0 || (long)d->Cout * P >= (1L << 30) || (long)d->Cin * P >= (1L << 30)) return false;
+    const int bm = 16 * wino_tm(M);
+    const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256);
     return tiles >= 1024;                                // (no split-K form)
 }
 
-size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) {
-    const int Mp = (d->Cin + 63) / 64 * 64, nblk = (d->Cout + 15) / 16;
+// dgrad / forward of a 1x3x3 stride-1 pad-(0,1,1) convolution with enough voxel tiles to fill the chip
+bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cin); }
+bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
+int wino_fwd_stat_tiles(const zsv_conv_desc* d) { return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256); }
+
+static size_t wino_bytes(int M, int C) {
+    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
     return wino_align((size_t)nblk * 3 * 4 * 16 * Mp * sizeof(float));
 }
+size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout); }
+size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin); }
 
-int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
-               size_t workspace_bytes, hipStream_t stream) {
-    if (!workspace || workspace_bytes < wino_dgrad_workspace_bytes(d)) return ZSV_E_WORKSPACE;
+template <int TM>
+static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    constexpr int LDA = (16 * TM) % 32 == 16 ? 16 * TM : 16 * TM + 16;          // as in the kernel
+    constexpr int LDS_BYTES = 2 * (4 * 16 * LDA + 16 * 288 + 64) * 4;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    const long tiles = (long)p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(conv_wino_kernel<TM>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    return launch_status();
+}
+
+// out[m] = sum_c G[m][c] (*) in[c]; G[m][c][tap] = w[m*sm + c*sc + (flip ? 8 - tap : tap)]
+static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
+                    const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, float* out,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!workspace || workspace_bytes < wino_bytes(M, C)) return ZSV_E_WORKSPACE;
+    const int tm = wino_tm(M), bm = 16 * tm;
     WinoParams p;
-    p.M = d->Cin;
-    p.Mp = (d->Cin + 63) / 64 * 64;
-    p.C = d->Cout;
-    p.nblk = (d->Cout + 15) / 16;
+    p.M = M;
+    p.Mp = (M + bm - 1) / bm * bm;
+    p.C = C;
+    p.nblk = (C + 15) / 16;
     p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.H = d->Hi;
     p.P = d->N * p.S;
-    p.in_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
-    p.tiles_m = p.Mp / 64;
-    p.add = add;
+    p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
+    p.tiles_m = p.Mp / bm;
+    p.tiles_n = (p.P + 255) / 256;
+    p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     float* up = (float*)workspace;
     const long total = (long)p.nblk * 3 * 4 * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    // G[m = ci][c = co][kh][kw] = W[co][ci][2-kh][2-kw]: stride of m is 9, of c is Cin*9, taps flipped
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 9L,
-                       (long)d->Cin * 9, 1, total);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, sm, sc, flip,
+                       total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    constexpr int LDS_BYTES = 2 * (4 * 16 * 80 + 16 * 288 + 64) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    const long tiles = (long)p.tiles_m * ((p.P + 255) / 256);
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, dy, dx);
-    return launch_status();
+    return tm == 3 ? wino_launch<3>(p, up, in, out, stream) : wino_launch<4>(p, up, in, out, stream);
+}
+
+int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
+               size_t workspace_bytes, hipStream_t stream) {
+    // G[m = ci][c = co][kh][kw] = W[co][ci][2-kh][2-kw]: stride of m is 9, of c is Cin*9, taps flipped
+    return wino_run(d, d->Cin, d->Cout, dy, w, 9L, (long)d->Cin * 9, 1, add, nullptr, 0, nullptr, nullptr, dx, workspace,
+                    workspace_bytes, stream);
+}
+
+int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,
+             float* stat_sum, float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return wino_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 9, 9L, 0, residual, bias, relu, stat_sum, stat_sq, y, workspace,
+                    workspace_bytes, stream);
 }
 
 }  // namespace zsv
