@@ -12,10 +12,11 @@ averaged across ranks by the bucketed RCCL all-reduce of ``ddp.GradientSync``, o
 with backward.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
 line.  Extra objects on that line:
 
-* ``roofline``  : the dominant kernel (the fp32-MFMA implicit-GEMM convolution on the
-  64->144 1x3x3 shape, 41 % of forward FLOPs): algorithmic FLOPs per launch / mean launch
-  duration from HIP events recorded on the launch stream inside the timed steps, against the
-  157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md);
+* ``roofline``  : the dominant kernel (the fp32-MFMA convolution on the 64->144 1x3x3 shape,
+  41 % of forward FLOPs; kw taps in Winograd F(2,3) form): algorithmic (direct-convolution)
+  FLOPs per launch / mean launch duration from HIP events recorded on the launch stream inside
+  the timed steps, against the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md); the FLOPs
+  the matrix pipe really executes (2/3 of them) are reported next to it;
 * ``cpu_baseline``: the CPU oracle (oracle/restatement.py, pinned to the reference) timed on
   this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only.
 """
@@ -97,7 +98,7 @@ def pmc_traffic(n_clips: int):
     path = os.path.join(ROOT, "profiles", "r01_s1_hbm_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]["conv_tap_dma_kernel<9, 2, 1, 4, 1, 4, 9>"]
+            k = json.load(f)["kernels"]["conv_wino_kernel<3, 12>"]
         return round(k["hbm_bytes"]) if n_clips == CLIPS_PER_GPU else None
     except Exception:
         return None
@@ -244,12 +245,19 @@ def main():
             ms = timer.durations_ms()
             mean_ms = sum(ms) / len(ms)
             n = args.batch
-            flops = 2.0 * n * 144 * 64 * 9 * 16 * 56 * 56          # 8.324 GFLOP/clip
+            flops = 2.0 * n * 144 * 64 * 9 * 16 * 56 * 56          # 8.324 GFLOP/clip: the direct-convolution count
             alg_bytes = 4.0 * (n * 64 * 16 * 56 * 56 + n * 144 * 16 * 56 * 56 + 144 * 64 * 9)
             achieved = flops / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "zsv::conv_tap_dma_kernel<9, 2, 1, 4, 1, 4, 9> = Conv3d(64,144,(1,3,3)) forward @16x56x56, 4 launches/step",
+            # the kernel computes the kw taps in Winograd F(2,3) form: 4 multiplies per output pair instead of 6,
+            # so the matrix pipe executes 2/3 of the algorithmic FLOPs (counter-checked: profiles/r01_s1_mfma_busy.json)
+            executed = flops * 2.0 / 3.0 / (mean_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "zsv::conv_wino_kernel<3, 12> = Conv3d(64,144,(1,3,3)) forward @16x56x56 "
+                                         "(fp32 Winograd F(2,3) along W + its weight-transform launch), 4 launches/step",
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                               "achieved_is": "algorithmic (direct-convolution) FLOPs / time, as SURVEY 8d counts them",
+                               "mfma_executed_tflops": round(executed, 2),
+                               "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                                "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
                                "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
                                "traffic": pmc_traffic(n)}

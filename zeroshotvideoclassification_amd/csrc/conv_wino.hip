@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     }
 }
 
-// TM = 16-row blocks per workgroup (rows = 16*TM: 64 for the gradients, 48 for the 144- and 288-channel forwards)
-template <int TM>
+// TM = 16-row blocks per workgroup (rows = 16*TM: 64 for the gradients, 48 for the 144- and 288-channel forwards);
+// NCHUNKS = K chunks when known at compile time (12: the 64-channel layer1 forward, which so has its own symbol), 0 = runtime
+template <int TM, int NCHUNKS>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const float* __restrict__ Up,
                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     }
     const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
 
-    const int nchunks = prm.nblk * 3;
+    const int nchunks = NCHUNKS > 0 ? NCHUNKS : prm.nblk * 3;
     int ld_cb = 0, ld_kh = 0;
     auto issue = [&](int chunk, int buf) {
         float* as = pool + buf * STAGE;
@@ -195,22 +196,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
         const float* as = pool + cur * STAGE;
         const float* bs = as + A_FLOATS;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        // fragments of k-step s+1 are fetched before the MFMA burst of step s (ZSV_WINO_PIPE)
+        float a[2][4][TM];
+        f32x2 lo[2][2], hi[2][2];
+        auto fetch = [&](int s, int slot) {
             const int krow = 4 * s + g;
-            float a[4][TM];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
-            float v[4][2];
+                for (int i = 0; i < TM; ++i) a[slot][p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float* src = bs + krow * LDB + 64 * wave + 2 * (16 * j + r16);       // image column of d0
-                const f32x2 lo = *reinterpret_cast<const f32x2*>(src), hi = *reinterpret_cast<const f32x2*>(src + 2);
-                const float d0 = zero_d0[j] ? 0.f : lo[0], d1 = lo[1], d2 = hi[0], d3 = zero_d3[j] ? 0.f : hi[1];
+                lo[slot][j] = *reinterpret_cast<const f32x2*>(src);
+                hi[slot][j] = *reinterpret_cast<const f32x2*>(src + 2);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sl = s & 1;
+            float v[4][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float d0 = zero_d0[j] ? 0.f : lo[sl][j][0], d1 = lo[sl][j][1], d2 = hi[sl][j][0], d3 = zero_d3[j] ? 0.f : hi[sl][j][1];
                 v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
             }
+            if (s < 3) fetch(s + 1, sl ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][i], v[p][j], acc[p][i][j], 0, 0, 0);
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][p][i], v[p][j], acc[p][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -299,7 +311,8 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (P % 2 != 0 || (long)d->Cout * P >= (1L << 30) || (long)d->Cin * P >= (1L << 30)) return false;
     const int bm = 16 * wino_tm(M);
     const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256);
-    return tiles >= 1024;                                // (no split-K form)
+    const char* e = getenv("ZSV_WINO_MIN_TILES");
+    return tiles >= (e ? atol(e) : 600);                 // (no split-K form)
 }
 
 // dgrad / forward of a 1x3x3 stride-1 pad-(0,1,1) convolution with enough voxel tiles to fill the chip
@@ -314,14 +327,14 @@ static size_t wino_bytes(int M, int C) {
 size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout); }
 size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin); }
 
-template <int TM>
+template <int TM, int NCHUNKS>
 static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     constexpr int LDA = (16 * TM) % 32 == 16 ? 16 * TM : 16 * TM + 16;          // as in the kernel
     constexpr int LDS_BYTES = 2 * (4 * 16 * LDA + 16 * 288 + 64) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(conv_wino_kernel<TM>, dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    hipLaunchKernelGGL((conv_wino_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
 
@@ -349,7 +362,8 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, sm, sc, flip,
                        total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    return tm == 3 ? wino_launch<3>(p, up, in, out, stream) : wino_launch<4>(p, up, in, out, stream);
+    if (tm == 3) return p.nblk == 4 ? wino_launch<3, 12>(p, up, in, out, stream) : wino_launch<3, 0>(p, up, in, out, stream);
+    return wino_launch<4, 0>(p, up, in, out, stream);
 }
 
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
