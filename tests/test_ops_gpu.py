@@ -462,8 +462,10 @@ def test_conv3d_wgrad_dma_random_geometries():
         done += 1
 
 
-@pytest.mark.parametrize("n,cin,cout,thw", [(4, 32, 16, (8, 96, 96)), (2, 100, 24, (4, 96, 180)), (6, 64, 48, (16, 56, 56))],
-                         ids=["one_row_tile", "two_row_tiles_padded_channels", "s1_like"])
+@pytest.mark.parametrize("n,cin,cout,thw", [(4, 32, 16, (8, 96, 96)), (2, 100, 24, (4, 96, 180)), (6, 64, 48, (16, 56, 56)),
+                                            (4, 32, 24, (8, 64, 90)), (4, 64, 20, (8, 64, 90))],
+                         ids=["one_row_tile", "two_row_tiles_padded_channels", "s1_like", "w_not_mult_of_4_48_rows",
+                              "w_not_mult_of_4_64_rows"])
 def test_conv3d_dgrad_winograd_path(n, cin, cout, thw, monkeypatch):
     """Input gradient of the 1x3x3 stride-1 convolutions through the Winograd F(2,3)-along-W kernel (large
     voxel counts only: it has no split-K form) against torch CPU fp64 and against the direct kernel; with
@@ -500,8 +502,10 @@ def test_conv3d_dgrad_winograd_path(n, cin, cout, thw, monkeypatch):
 
 
 @pytest.mark.parametrize("n,cin,cout,thw", [(4, 16, 32, (8, 96, 96)), (2, 24, 100, (4, 96, 180)), (6, 64, 144, (16, 56, 56)),
-                                            (4, 45, 288, (8, 28, 56))],
-                         ids=["one_48_row_tile", "padded_channels_64_rows", "s1_48_row_tiles", "288_rows_ragged_k"])
+                                            (4, 45, 288, (8, 28, 56)), (4, 20, 40, (8, 64, 90)), (4, 24, 64, (8, 64, 90)),
+                                            (22, 256, 460, (4, 14, 14))],
+                         ids=["one_48_row_tile", "padded_channels_64_rows", "s1_48_row_tiles", "288_rows_ragged_k",
+                              "w_not_mult_of_4_48_rows", "w_not_mult_of_4_64_rows", "layer3_shape"])
 def test_conv3d_fwd_winograd_path(n, cin, cout, thw, monkeypatch):
     """Forward of the 1x3x3 stride-1 convolutions through the Winograd F(2,3)-along-W kernel (64- and 48-row
     tiles) against torch CPU fp64 and the direct kernel: plain, with the BatchNorm partial statistics of the

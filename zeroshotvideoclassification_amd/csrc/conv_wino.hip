@@ -68,19 +68,22 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 }
 
 // TM = 16-row blocks per workgroup (rows = 16*TM: 64 for the gradients, 48 for the 144- and 288-channel forwards);
-// NCHUNKS = K chunks when known at compile time (12: the 64-channel layer1 forward, which so has its own symbol), 0 = runtime
-template <int TM, int NCHUNKS>
+// NCHUNKS = K chunks when known at compile time (12: the 64-channel layer1 forward, which so has its own symbol), 0 = runtime;
+// X4 = the raw image is staged by 16-byte DMAs (W % 4 == 0: the 4 voxels of a piece share their row, so one validity bit and
+// one 16-byte-aligned address serve them): 4 instead of 16 activation DMAs per wave and chunk
+template <int TM, int NCHUNKS, bool X4>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const float* __restrict__ Up,
                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 16 * TM, BN = 256, BK = 16;
     constexpr int LDA = BM % 32 == 16 ? BM : BM + 16;   // k-major rows, ds_read_b32 conflict-free (pitch = 16 mod 32)
     static_assert(LDA % 32 == 16, "A pitch");
-    constexpr int LDB = 288;                // 258 used; = 32 mod 64 so the two k rows of a ds_read_b64 pass split the banks
+    constexpr int LDB = 288;                // 258 (261) used; = 32 mod 64 so the two k rows of a ds_read_b64 pass split the banks
+    constexpr int C0 = X4 ? 4 : 1;          // image column of the tile's first voxel (16-byte aligned for the 16-byte DMAs); halo at C0-1, C0+256
     constexpr int A_FLOATS = 4 * BK * LDA, B_FLOATS = BK * LDB;
     constexpr int HALO_AT = A_FLOATS + B_FLOATS;      // 64 floats of scratch: where the halo DMA lands
     constexpr int STAGE = HALO_AT + 64;
-    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr unsigned OOB = 0xFFFFFFFFu, OOB16 = 0xFFFFFFF0u;      // (+12 must not wrap)
     extern __shared__ __attribute__((aligned(16))) float pool[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
     const int ch_bytes = 4 * prm.S;
 
-    // ---- this lane's voxel of the raw image: column 1 + 64*wave + lane --------------------------
+    // ---- this lane's voxel(s) of the raw image: column C0 + 64*wave + lane (X4: C0 + 4*lane .. + 3, every k row) ----
     auto decode = [&](int p, int& base_bytes, unsigned& hmask) {
         base_bytes = 0;
         hmask = 0;
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     };
     int base_bytes;
     unsigned hmask;
-    decode(n0 + 64 * wave + lane, base_bytes, hmask);
-    // halo columns 0 and 257 (voxels n0-1, n0+256): wave 0, lanes 0..31 = (k row, side)
+    decode(X4 ? n0 + 4 * lane : n0 + 64 * wave + lane, base_bytes, hmask);
+    // halo columns C0-1 and C0+256 (voxels n0-1, n0+256): wave 0, lanes 0..31 = (k row, side)
     int halo_base = 0;
     unsigned halo_mask = 0;
     if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
@@ -134,14 +137,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         float* bs = as + A_FLOATS;
         const int toff = 4 * (ld_kh - 1) * prm.W;
         const unsigned ok = (hmask >> ld_kh) & 1u;
-        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);
         const int ci0 = ld_cb * 16;
+        if constexpr (X4) {
+            const unsigned voff = ok ? (unsigned)(base_bytes + toff) : OOB16;
 #pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            const int ci = ci0 + k;
-            const unsigned v = ci < prm.C ? voff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + 1 + 64 * wave), 4, (int)v,
-                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0), 16, (int)(ci < prm.C ? voff : OOB16),
+                                                         ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+            }
+        } else {
+            const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);
+#pragma unroll
+            for (int k = 0; k < BK; ++k) {
+                const int ci = ci0 + k;
+                const unsigned v = ci < prm.C ? voff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0 + 64 * wave), 4, (int)v,
+                                                         ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+            }
         }
         if (wave == 0) {
             // one instruction: lanes 0..31 -> (k = lane/2, side = lane&1); the destination must be lane-linear,
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         if (wave == 0 && lane < 32) {
             float* bs = pool + buf * STAGE + A_FLOATS;
             const float v = pool[buf * STAGE + HALO_AT + lane];
-            bs[(lane >> 1) * LDB + ((lane & 1) ? BN + 1 : 0)] = v;
+            bs[(lane >> 1) * LDB + ((lane & 1) ? C0 + BN : C0 - 1)] = v;
         }
     };
 
@@ -207,9 +220,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
                 for (int i = 0; i < TM; ++i) a[slot][p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float* src = bs + krow * LDB + 64 * wave + 2 * (16 * j + r16);       // image column of d0
-                lo[slot][j] = *reinterpret_cast<const f32x2*>(src);
-                hi[slot][j] = *reinterpret_cast<const f32x2*>(src + 2);
+                const float* src = bs + krow * LDB + (C0 - 1) + 64 * wave + 2 * (16 * j + r16);       // image column of d0
+                if constexpr (X4) {                       // d0 sits at an odd column: aligned (d1, d2) + two single reads
+                    const f32x2 mid = *reinterpret_cast<const f32x2*>(src + 1);
+                    lo[slot][j] = f32x2{src[0], mid[0]};
+                    hi[slot][j] = f32x2{mid[1], src[3]};
+                } else {
+                    lo[slot][j] = *reinterpret_cast<const f32x2*>(src);
+                    hi[slot][j] = *reinterpret_cast<const f32x2*>(src + 2);
+                }
             }
         };
         fetch(0, 0);
@@ -327,14 +346,14 @@ static size_t wino_bytes(int M, int C) {
 size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout); }
 size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin); }
 
-template <int TM, int NCHUNKS>
+template <int TM, int NCHUNKS, bool X4>
 static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     constexpr int LDA = (16 * TM) % 32 == 16 ? 16 * TM : 16 * TM + 16;          // as in the kernel
     constexpr int LDS_BYTES = 2 * (4 * 16 * LDA + 16 * 288 + 64) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM, NCHUNKS, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((conv_wino_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    hipLaunchKernelGGL((conv_wino_kernel<TM, NCHUNKS, X4>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
 
@@ -362,8 +381,12 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, sm, sc, flip,
                        total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    if (tm == 3) return p.nblk == 4 ? wino_launch<3, 12>(p, up, in, out, stream) : wino_launch<3, 0>(p, up, in, out, stream);
-    return wino_launch<4, 0>(p, up, in, out, stream);
+    const bool x4 = d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_X4") == nullptr;
+    if (tm == 3) {
+        if (x4) return p.nblk == 4 ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
+        return wino_launch<3, 0, false>(p, up, in, out, stream);
+    }
+    return x4 ? wino_launch<4, 0, true>(p, up, in, out, stream) : wino_launch<4, 0, false>(p, up, in, out, stream);
 }
 
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
