@@ -552,3 +552,38 @@ def test_conv3d_fwd_winograd_path(n, cin, cout, thw, monkeypatch):
     direct, _ = run("plain")
     close(fast, direct.double(), rtol=5e-6, what="winograd vs direct kernel")
     assert not torch.equal(fast, direct), "the two paths should not be the same kernel"
+
+
+@pytest.mark.parametrize("n,cin,cout,thw", [(4, 16, 32, (8, 64, 96)), (6, 24, 64, (5, 64, 90)), (2, 64, 128, (16, 56, 56))],
+                         ids=["small_channels", "odd_frames_w_not_mult_of_4", "c3d_conv2_like"])
+def test_conv3d_333_winograd_path(n, cin, cout, thw, monkeypatch):
+    """3x3x3 stride-1 "same" convolutions (C3D network.py:102-117, Conv3DSimple resnet.py:23-30) through the
+    Winograd kernel (9 (kt, kh) row taps): relu(conv + bias) forward and both gradients through autograd
+    against torch CPU fp64, and forward / input gradient against the direct kernel."""
+    t, h, w = thw
+    g = torch.Generator().manual_seed(cin * 13 + cout)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) / np.sqrt(cin * 27)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    bias = torch.randn(cout, generator=g) * 0.1
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    yr = torch.relu(F.conv3d(x.double(), wt.double(), bias.double(), padding=1))
+
+    def run():
+        xg, wg, bg = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), bias.to(DEV).requires_grad_()
+        y = ops.conv3d(xg, wg, bg, 1, 1, relu=True)
+        y.backward(dy.to(DEV))
+        return y.detach(), xg.grad, wg.grad, bg.grad
+
+    y, dx, dw, db = run()
+    close(y, yr, what="3x3x3 winograd fwd (+bias, relu)")
+    # the gradients' reference uses the device's own ReLU mask (outputs within rounding of 0 may differ in sign)
+    gm = dy.double() * (y.cpu() > 0)
+    close(dx, torch.nn.grad.conv3d_input(x.shape, wt.double(), gm, padding=1), what="3x3x3 winograd dgrad")
+    close(dw, torch.nn.grad.conv3d_weight(x.double(), wt.shape, gm, padding=1), rtol=5e-5, what="3x3x3 wgrad")
+    close(db, gm.sum(dim=(0, 2, 3, 4)), rtol=5e-5, what="3x3x3 dbias")
+    monkeypatch.setenv("ZSV_NO_WINO", "1")
+    y2, dx2, _, _ = run()
+    close(y, y2.double(), rtol=5e-6, what="winograd vs direct kernel (fwd)")
+    if torch.equal(y > 0, y2 > 0):
+        close(dx, dx2.double(), rtol=5e-6, what="winograd vs direct kernel (dgrad)")
+    assert not torch.equal(y, y2), "the two paths should not be the same kernel"

@@ -1,8 +1,9 @@
-// conv_wino.hip -- 1x3x3 stride-1 "same" convolution with the kw taps in Winograd F(2,3) form (fp32).
+// conv_wino.hip -- 1x3x3 / 3x3x3 stride-1 "same" convolution with the kw taps in Winograd F(2,3) form (fp32).
 //
 //   out[m][t,h,w] = sum_{c,kh,kw} G[m][c][kh][kw] * in[c][t, h+kh-1, w+kw-1]
-// (used for the input gradient of Conv2Plus1D's spatial convolution, resnet.py:40-45: in = dy, m = input
-// channel, G = the weights with both spatial axes flipped).  Along W two adjacent outputs share their
+// (forward and input gradient of Conv2Plus1D's spatial convolution, resnet.py:40-45 -- for the gradient in = dy,
+// m = input channel, G = the weights with the tap axes flipped; with kT = 3 the (kt, kh) pairs take the place of
+// kh: Conv3DSimple resnet.py:23-30, C3D network.py:102-117).  Along W two adjacent outputs share their
 // inputs: with d0..d3 = in[w-1..w+2] of one (c, kh) row and g0..g2 the three kw weights,
 //     V0 = d0-d2   V1 = d1+d2   V2 = d2-d1   V3 = d1-d3
 //     U0 = g0      U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2
@@ -31,7 +32,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct WinoParams {
     int M, Mp;              // output channels, padded to 64
     int C, nblk;            // reduction channels, 16-channel blocks
-    int S, HW, W, H;        // voxels per clip / frame, row length, rows
+    int S, HW, W, H, T;     // voxels per clip / frame, row length, rows, frames
+    int kT, R;              // temporal taps (1 or 3, pad kT/2), row taps R = 3*kT (a row tap = one (kt, kh))
     int P;                  // N * S
     unsigned in_bytes;
     int tiles_m, tiles_n;
@@ -42,9 +44,9 @@ struct WinoParams {
     float* stat_sq;         //   [M][tiles_n] each (BatchNorm statistics of a training forward)
 };
 
-// Up[((cb*3 + kh)*4 + pt)*16 + c%16][Mp] from G[m][c][kh][kw] = W[m*sm + c*sc + (flip ? 8 - (3*kh+kw) : 3*kh+kw)]
+// Up[((cb*R + r)*4 + pt)*16 + c%16][Mp] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
-                                                        int C, int nblk, long sm, long sc, int flip, long total) {
+                                                        int C, int nblk, int R, long sm, long sc, int flip, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int m = (int)(i % Mp);
         long r = i / Mp;
@@ -52,14 +54,15 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
         r /= 16;
         const int pt = (int)(r % 4);
         r /= 4;
-        const int kh = (int)(r % 3);
-        const int cb = (int)(r / 3);
+        const int kh = (int)(r % R);
+        const int cb = (int)(r / R);
         const int c = cb * 16 + c16;
         float v = 0.f;
         if (m < M && c < C) {
             const float* g = W + (size_t)m * sm + (size_t)c * sc;
-            const int k0 = flip ? 8 - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? 8 - (3 * kh + 1) : 3 * kh + 1,
-                      k2 = flip ? 8 - (3 * kh + 2) : 3 * kh + 2;
+            const int last = 3 * R - 1;
+            const int k0 = flip ? last - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? last - (3 * kh + 1) : 3 * kh + 1,
+                      k2 = flip ? last - (3 * kh + 2) : 3 * kh + 2;
             const float g0 = g[k0], g1 = g[k1], g2 = g[k2];
             v = pt == 0 ? g0 : pt == 1 ? 0.5f * ((g0 + g2) + g1) : pt == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
         }
@@ -106,7 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
             r -= t * prm.HW;
             const int h = r / prm.W;
             base_bytes = 4 * (n * prm.C * prm.S + (p - n * prm.S));
-            for (int kh = 0; kh < 3; ++kh) hmask |= (unsigned)((unsigned)(h + kh - 1) < (unsigned)prm.H) << kh;
+            for (int kt = 0; kt < prm.kT; ++kt)
+                for (int kh = 0; kh < 3; ++kh)
+                    hmask |= (unsigned)((unsigned)(h + kh - 1) < (unsigned)prm.H && (unsigned)(t + kt - prm.kT / 2) < (unsigned)prm.T) << (kt * 3 + kh);
         }
     };
     int base_bytes;
@@ -130,13 +135,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     }
     const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
 
-    const int nchunks = NCHUNKS > 0 ? NCHUNKS : prm.nblk * 3;
-    int ld_cb = 0, ld_kh = 0;
+    const int nchunks = NCHUNKS > 0 ? NCHUNKS : prm.nblk * prm.R;
+    int ld_cb = 0, ld_kh = 0, ld_kt = 0;
     auto issue = [&](int chunk, int buf) {
         float* as = pool + buf * STAGE;
         float* bs = as + A_FLOATS;
-        const int toff = 4 * (ld_kh - 1) * prm.W;
-        const unsigned ok = (hmask >> ld_kh) & 1u;
+        const int toff = 4 * ((ld_kh - 1) * prm.W + (ld_kt - prm.kT / 2) * prm.HW);
+        const int ld_r = ld_kt * 3 + ld_kh;
+        const unsigned ok = (hmask >> ld_r) & 1u;
         const int ci0 = ld_cb * 16;
         if constexpr (X4) {
             const unsigned voff = ok ? (unsigned)(base_bytes + toff) : OOB16;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
             // so the 32 halo values land in a scratch row and are moved by 32 lanes after the wait
             const int k = lane >> 1;
             const int ci = ci0 + k;
-            const unsigned hok = (halo_mask >> ld_kh) & 1u;
+            const unsigned hok = (halo_mask >> ld_r) & 1u;
             unsigned hv = (unsigned)(halo_base + toff) | (hok - 1u);
             if (lane >= 32 || ci >= prm.C) hv = OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(as + HALO_AT), 4, (int)(hv + (hv == OOB ? 0u : (unsigned)(ci * ch_bytes))), 0, 0, 0);
@@ -170,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         for (int j = 0; j < APASS; ++j)
             if (64 * (wave + 4 * j) < ASLOTS)              // wave-uniform
                 __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
-        if (++ld_kh == 3) { ld_kh = 0; ++ld_cb; }
+        if (++ld_kh == 3) {
+            ld_kh = 0;
+            if (++ld_kt == prm.kT) { ld_kt = 0; ++ld_cb; }
+        }
     };
     // after the DMAs of a stage have landed: scatter the 32 halo values into columns 0 / 257 of their rows
     auto place_halo = [&](int buf) {
@@ -322,8 +331,8 @@ static int wino_tm(int M) {
 
 static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (getenv("ZSV_NO_WINO")) return false;
-    if (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 0 || d->pH != 1 ||
-        d->pW != 1)
+    if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
+        d->pH != 1 || d->pW != 1)
         return false;
     if (d->Wi % 2 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
@@ -331,20 +340,20 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
     const int bm = 16 * wino_tm(M);
     const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256);
     const char* e = getenv("ZSV_WINO_MIN_TILES");
-    return tiles >= (e ? atol(e) : 600);                 // (no split-K form)
+    return tiles >= (e ? atol(e) : 512);                 // (no split-K form)
 }
 
-// dgrad / forward of a 1x3x3 stride-1 pad-(0,1,1) convolution with enough voxel tiles to fill the chip
+// dgrad / forward of a 1x3x3 or 3x3x3 stride-1 "same" convolution with enough voxel tiles to fill the chip
 bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cin); }
 bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
 int wino_fwd_stat_tiles(const zsv_conv_desc* d) { return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256); }
 
-static size_t wino_bytes(int M, int C) {
+static size_t wino_bytes(int M, int C, int kT) {
     const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
-    return wino_align((size_t)nblk * 3 * 4 * 16 * Mp * sizeof(float));
+    return wino_align((size_t)nblk * 3 * kT * 4 * 16 * Mp * sizeof(float));
 }
-size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout); }
-size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin); }
+size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout, d->kT); }
+size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin, d->kT); }
 
 template <int TM, int NCHUNKS, bool X4>
 static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
@@ -357,33 +366,34 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
     return launch_status();
 }
 
-// out[m] = sum_c G[m][c] (*) in[c]; G[m][c][tap] = w[m*sm + c*sc + (flip ? 8 - tap : tap)]
+// out[m] = sum_c G[m][c] (*) in[c]; G[m][c][tap] = w[m*sm + c*sc + (flip ? 9*kT-1 - tap : tap)]
 static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
                     const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, float* out,
                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!workspace || workspace_bytes < wino_bytes(M, C)) return ZSV_E_WORKSPACE;
+    if (!workspace || workspace_bytes < wino_bytes(M, C, d->kT)) return ZSV_E_WORKSPACE;
     const int tm = wino_tm(M), bm = 16 * tm;
     WinoParams p;
     p.M = M;
     p.Mp = (M + bm - 1) / bm * bm;
     p.C = C;
     p.nblk = (C + 15) / 16;
-    p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.H = d->Hi;
+    p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.H = d->Hi; p.T = d->Ti;
+    p.kT = d->kT; p.R = 3 * d->kT;
     p.P = d->N * p.S;
     p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
     p.tiles_m = p.Mp / bm;
     p.tiles_n = (p.P + 255) / 256;
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     float* up = (float*)workspace;
-    const long total = (long)p.nblk * 3 * 4 * 16 * p.Mp;
+    const long total = (long)p.nblk * p.R * 4 * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, sm, sc, flip,
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, p.R, sm, sc, flip,
                        total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const bool x4 = d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_X4") == nullptr;
     if (tm == 3) {
-        if (x4) return p.nblk == 4 ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
+        if (x4) return p.nblk * p.R == 12 ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
         return wino_launch<3, 0, false>(p, up, in, out, stream);
     }
     return x4 ? wino_launch<4, 0, true>(p, up, in, out, stream) : wino_launch<4, 0, false>(p, up, in, out, stream);
@@ -391,14 +401,16 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
 
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream) {
-    // G[m = ci][c = co][kh][kw] = W[co][ci][2-kh][2-kw]: stride of m is 9, of c is Cin*9, taps flipped
-    return wino_run(d, d->Cin, d->Cout, dy, w, 9L, (long)d->Cin * 9, 1, add, nullptr, 0, nullptr, nullptr, dx, workspace,
+    // G[m = ci][c = co][kt][kh][kw] = W[co][ci][kT-1-kt][2-kh][2-kw]: stride of m is 9*kT, of c is Cin*9*kT, taps flipped
+    const long taps = 9L * d->kT;
+    return wino_run(d, d->Cin, d->Cout, dy, w, taps, (long)d->Cin * taps, 1, add, nullptr, 0, nullptr, nullptr, dx, workspace,
                     workspace_bytes, stream);
 }
 
 int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,
              float* stat_sum, float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return wino_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 9, 9L, 0, residual, bias, relu, stat_sum, stat_sq, y, workspace,
+    const long taps = 9L * d->kT;
+    return wino_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * taps, taps, 0, residual, bias, relu, stat_sum, stat_sq, y, workspace,
                     workspace_bytes, stream);
 }
 
