@@ -57,7 +57,7 @@ def parse():
                     help="fused: zeroshotvideoclassification_amd.optim.FusedAdam (one launch, same update rule as "
                          "torch.optim.Adam); torch: torch.optim.Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args()
 
 

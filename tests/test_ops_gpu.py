@@ -587,3 +587,38 @@ def test_conv3d_333_winograd_path(n, cin, cout, thw, monkeypatch):
     if torch.equal(y > 0, y2 > 0):
         close(dx, dx2.double(), rtol=5e-6, what="winograd vs direct kernel (dgrad)")
     assert not torch.equal(y, y2), "the two paths should not be the same kernel"
+
+
+WGRAD_WINO_CASES = [
+    # name, N, Cin, (T,H,W), Cout, kT
+    ("s1_like", 3, 64, (4, 56, 56), 144, 1),                 # 144-row tile, 3 column tiles
+    ("m230_cin45", 6, 45, (8, 28, 28), 230, 1),              # two 128-row tiles (ragged), channel padding, ragged column tile
+    ("c3d_333", 2, 32, (8, 32, 64), 128, 3),                 # 9 row taps
+    ("two_frames_333", 8, 16, (2, 32, 64), 120, 3),          # every voxel touches a temporal border
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO_CASES, ids=[c[0] for c in WGRAD_WINO_CASES])
+def test_conv3d_wgrad_winograd_path(case, monkeypatch):
+    """Weight gradient of the 1x3x3 / 3x3x3 stride-1 convolutions through the Winograd-form kernel
+    (conv_wgrad_wino.hip) against torch CPU fp64 and the plain LDS-DMA kernel; bitwise reproducible."""
+    name, n, cin, (t, h, w), cout, kt = case
+    g = torch.Generator().manual_seed(len(name) * 101 + cin)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    wshape = (cout, cin, kt, 3, 3)
+    pad = (kt // 2, 1, 1)
+    ref = torch.nn.grad.conv3d_weight(x.double(), wshape, dy.double(), padding=pad)
+
+    def run():
+        wg = torch.zeros(wshape, device=DEV).requires_grad_()
+        ops.conv3d(x.to(DEV), wg, None, 1, pad).backward(dy.to(DEV))
+        return wg.grad
+
+    a = run()
+    close(a, ref, what=f"{name} wgrad (winograd)")
+    assert torch.equal(a, run()), "bitwise reproducible"
+    monkeypatch.setenv("ZSV_NO_WGRAD_WINO", "1")
+    b = run()
+    close(b, ref, what=f"{name} wgrad (plain)")
+    assert not torch.equal(a, b), "the two paths should not be the same kernel"

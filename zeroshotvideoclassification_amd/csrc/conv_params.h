@@ -199,5 +199,14 @@ bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* d
 size_t wgrad_dma_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* workspace, size_t workspace_bytes,
               int* slices_out, int* cpad_out, hipStream_t stream);
+// per-voxel tap-validity words of one clip (S words; bit tap <=> the tap's input voxel is inside): used by both
+// LDS-DMA weight-gradient kernels
+int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream);
+// Winograd-form weight gradient of the 1x3x3 / 3x3x3 stride-1 "same" convolutions (conv_wgrad_wino.hip): slabs, mask
+// table, ordered reduction and output transform; writes dw
+bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
+size_t wgrad_wino_workspace_bytes(const zsv_conv_desc* d);
+int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+               hipStream_t stream);
 
 }  // namespace zsv

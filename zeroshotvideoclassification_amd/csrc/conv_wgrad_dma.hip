@@ -395,6 +395,13 @@ static int wgrad_dma_launch_tn(int tn, const WgradDmaParams& p, int slices, hipS
     return wgrad_dma_launch<TM, 2>(p, slices, stream, x, dy, vm, out);
 }
 
+int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream) {
+    const int S = d->Ti * d->Hi * d->Wi;
+    hipLaunchKernelGGL(wgrad_vmask_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, stream, S, d->Ti, d->Hi, d->Wi,
+                       d->kT, d->kH, d->kW, d->pT, d->pH, d->pW, out);
+    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+}
+
 // slabs + mask table live in `workspace`; returns the slab geometry for slab_sum_kernel
 int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* workspace, size_t workspace_bytes,
               int* slices_out, int* cpad_out, hipStream_t stream) {
@@ -411,10 +418,8 @@ int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* wor
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
     float* slabs = (float*)workspace;
     unsigned* vm = (unsigned*)((char*)workspace + align256((size_t)pl.slices * d->Cout * pl.Kp * sizeof(float)));
-    hipLaunchKernelGGL(wgrad_vmask_kernel, dim3((unsigned)((p.S + 255) / 256)), dim3(256), 0, stream, p.S, d->Ti, d->Hi,
-                       d->Wi, d->kT, d->kH, d->kW, d->pT, d->pH, d->pW, vm);
-    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    int st;
+    int st = wgrad_vmask(d, vm, stream);
+    if (st) return st;
     switch (pl.tm) {
         case 9: st = wgrad_dma_launch_tn<9>(pl.tn, p, pl.slices, stream, x, dy, vm, slabs); break;
         case 8: st = wgrad_dma_launch_tn<8>(pl.tn, p, pl.slices, stream, x, dy, vm, slabs); break;

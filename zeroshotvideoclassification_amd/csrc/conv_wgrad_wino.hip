@@ -1,0 +1,336 @@
+// conv_wgrad_wino.hip -- weight gradient of 1x3x3 / 3x3x3 stride-1 "same" convolutions with the kw taps in
+// Winograd form (the transpose of F(2,3) along W), fp32.
+//
+//   dW[co][ci][r][kw] = sum_p dY[co][p] * X[ci][p + d(r) + kw - 1]        r = (kt, kh) row tap, d(r) its voxel shift
+// (aten::convolution_backward, weight part, for resnet.py:23-30,40-45 and network.py:102-117).  Take the output voxels in
+// pairs (2q, 2q+1) along W -- W is even, a pair never straddles a row -- with y0, y1 = dY at the pair and d0..d3 =
+// X[2q-1 .. 2q+2] of one (ci, r) row (zero outside the image):
+//     A = (y0, y0+y1, y0-y1, y1)        V = (d0-d2, d1+d2, d2-d1, d1-d3)        Mi = sum_q Ai * Vi
+//     dW[kw=0] = M0 + (M1+M2)/2     dW[kw=1] = (M1-M2)/2     dW[kw=2] = (M1+M2)/2 - M3
+// 4 multiplies per pair and (co, ci, r) instead of 6: 1.5x fewer MFMAs than conv_wgrad_dma.hip, still fp32 in / fp32
+// accumulate (V is the same transform as the forward's, conv_wino.hip).
+//
+// GEMM per point: rows = 16*TM output channels, columns = 64 (r, ci) pairs per workgroup (one 16-column block per wave),
+// reduction over voxel pairs, cut into slices (one round of workgroups covers the problem); every slice writes its
+// partial [point][co][(r, ci)] slab and wgrad_wino_sum_kernel adds the slabs in a fixed order and applies the output
+// transform: bitwise reproducible, no float atomics.
+//   * MFMA k order as in conv_wgrad_dma.hip: k = 4*(lane>>4) + step, so a lane needs 4 consecutive PAIRS = 8 voxels
+//     of its row for the 4 steps of a 32-voxel chunk: two ds_read_b128 per fragment (+ the two halo voxels of the X row).
+//   * Both operands are rows contiguous along the reduction and are staged by 16-byte LDS-DMAs (buffer_load_dwordx4 ... lds:
+//     a piece outside the tensor reads as zeros) into padded rows: dY 36 floats (32 + one dummy piece), X 44 floats
+//     (voxels p-4 .. p+39 of the shifted row) -- pitches of 36 / 44 banks make the ds_read_b128 fragments conflict-free.
+//   * Borders: the per-voxel tap-validity words of conv_wgrad_dma.hip (wgrad_vmask_kernel) are DMA'd with the operands;
+//     d0 / (d1, d2) / d3 of a pair are zeroed by the bits (r, kw=0) / (r, kw=1) of its first and (r, kw=2) of its second
+//     voxel.  Rows read past a row / plane / clip pick up neighbouring values, which the same bits discard.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "conv_params.h"
+#include "zsv_common.h"
+#include "zsv_hip.h"
+
+namespace zsv {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
+struct WgradWinoParams {
+    int M, Cin, Cpad, R, Kp;          // Kp = R * Cpad columns, row-tap major
+    int S, HW, W, kT;
+    int chunks_total, chunks_per_slice;      // 32-voxel chunks
+    unsigned x_bytes, dy_bytes, vm_bytes;
+    int tiles_m, tiles_mn;
+};
+
+template <int TM>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams prm, const float* __restrict__ X,
+                                                                 const float* __restrict__ DY,
+                                                                 const unsigned* __restrict__ VM, float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 16 * TM;
+    constexpr int LDA = 36, LDB = 44;                       // floats per LDS row (9 / 11 pieces of 16 bytes)
+    constexpr int NA_TOT = (BM * 9 + 63) / 64;              // 1-KiB DMA instructions per stage: dY rows
+    constexpr int NB_TOT = 11;                              //                                    X rows (64 x 11 pieces)
+    constexpr int NA = (NA_TOT + 3) / 4, NB = 3;            // per wave
+    constexpr int A_BYTES = NA_TOT * 1024, B_BYTES = NB_TOT * 1024;
+    constexpr int VM_AT = A_BYTES + B_BYTES;
+    constexpr int STAGE = VM_AT + 1024;
+    constexpr unsigned OOB = 0xFFFFFFF0u;                   // (+12 must not wrap)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x % prm.tiles_mn, slice = blockIdx.x / prm.tiles_mn;
+    const int m0 = (tile % prm.tiles_m) * BM, n0 = (tile / prm.tiles_m) * 64;
+    const int c0 = slice * prm.chunks_per_slice;
+    const int nq = min(prm.chunks_per_slice, prm.chunks_total - c0);
+    const int cpc = prm.S / 32;                             // chunks per clip
+    int n_img = c0 / cpc;
+    int p_local = (c0 - n_img * cpc) * 32;
+
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY), 0, prm.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, prm.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_vm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(VM), 0, prm.vm_bytes, 0x00020000);
+
+    // ---- DMA assignment: piece id = 64 * instruction + lane -> (row, 16-byte piece of the row) ------------------
+    int a_off[NA];                      // byte offset inside clip 0 at p_local = 0, or -1: reads as zeros
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int id = 64 * (wave + 4 * k) + lane;
+        const int row = id / 9, pc = id - row * 9;
+        const bool ok = row < BM && m0 + row < prm.M && pc < 8;
+        a_off[k] = ok ? 4 * ((m0 + row) * prm.S + 4 * pc) : -1;
+    }
+    int b_off[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int id = 64 * (wave + 4 * k) + lane;
+        const int row = id / 11, pc = id - row * 11;
+        const int n = n0 + row;
+        const int r = n / prm.Cpad, ci = n - r * prm.Cpad;
+        const int kt = r / 3, kh = r - 3 * kt;
+        const int delta = (kt - prm.kT / 2) * prm.HW + (kh - 1) * prm.W;
+        b_ok[k] = row < 64 && n < prm.Kp && ci < prm.Cin;
+        b_off[k] = 4 * (ci * prm.S + delta + 4 * pc - 4);          // may be negative at p_local = 0 (then out of range)
+    }
+
+    auto issue = [&](int buf) {
+        unsigned char* base = lds + buf * STAGE;
+        const int a_chunk = 4 * (n_img * prm.M * prm.S + p_local);
+        const int b_chunk = 4 * (n_img * prm.Cin * prm.S + p_local);
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (wave + 4 * k < NA_TOT)                              // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(base + 1024 * (wave + 4 * k)), 16,
+                                                         (int)(a_off[k] >= 0 ? (unsigned)(a_off[k] + a_chunk) : OOB), 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (wave + 4 * k < NB_TOT) {
+                const int off = b_off[k] + b_chunk;                 // negative = before the tensor: reads as zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(base + A_BYTES + 1024 * (wave + 4 * k)), 16,
+                                                         (int)((b_ok[k] && off >= 0) ? (unsigned)off : OOB), 0, 0, 0);
+            }
+        if (wave == 0)                                              // 32 mask words: lanes 0..7
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vm, (lds_ptr_t)(base + VM_AT), 16,
+                                                     (int)(lane < 8 ? (unsigned)(4 * (p_local + 4 * lane)) : OOB), 0, 0, 0);
+        p_local += 32;
+        if (p_local == prm.S) { p_local = 0; ++n_img; }
+    };
+
+    f32x4 acc[4][TM];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    const int r_tap = min((n0 + 16 * wave) / prm.Cpad, 8);           // row tap of this wave's 16 columns (Cpad % 16 == 0)
+    const unsigned bit0 = 1u << (3 * r_tap), bit1 = 2u << (3 * r_tap), bit2 = 4u << (3 * r_tap);
+    const int a_frag = (r16 * LDA + 8 * g) * 4;                       // bytes inside the A image (+ 16 * LDA * 4 per block)
+    const int b_frag = A_BYTES + ((16 * wave + r16) * LDB + 8 * g + 4) * 4;
+    const int v_frag = VM_AT + g * 32;
+
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < nq; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nq) issue(cur ^ 1);
+        const unsigned char* st = lds + cur * STAGE;
+        // this lane's 8 voxels (4 pairs) of its X row, their halo and their mask words
+        const u32x4w vm0 = *reinterpret_cast<const u32x4w*>(st + v_frag), vm1 = *reinterpret_cast<const u32x4w*>(st + v_frag + 16);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + b_frag), b1 = *reinterpret_cast<const f32x4*>(st + b_frag + 16);
+        const float bl = *reinterpret_cast<const float*>(st + b_frag - 4), br = *reinterpret_cast<const float*>(st + b_frag + 32);
+        f32x4 ar[2][2];
+        ar[0][0] = *reinterpret_cast<const f32x4*>(st + a_frag);
+        ar[0][1] = *reinterpret_cast<const f32x4*>(st + a_frag + 16);
+        const float xv[10] = {bl, b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], br};
+        const unsigned mw[8] = {vm0[0], vm0[1], vm0[2], vm0[3], vm1[0], vm1[1], vm1[2], vm1[3]};
+        float V[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned ma = mw[2 * s], mb = mw[2 * s + 1];
+            const float d0 = (ma & bit0) ? xv[2 * s] : 0.f, d1 = (ma & bit1) ? xv[2 * s + 1] : 0.f,
+                        d2 = (ma & bit1) ? xv[2 * s + 2] : 0.f, d3 = (mb & bit2) ? xv[2 * s + 3] : 0.f;
+            V[0][s] = d0 - d2; V[1][s] = d1 + d2; V[2][s] = d2 - d1; V[3][s] = d1 - d3;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int sl = i & 1;
+            if (i + 1 < TM) {
+                ar[sl ^ 1][0] = *reinterpret_cast<const f32x4*>(st + a_frag + (i + 1) * 16 * LDA * 4);
+                ar[sl ^ 1][1] = *reinterpret_cast<const f32x4*>(st + a_frag + (i + 1) * 16 * LDA * 4 + 16);
+            }
+            const float y[8] = {ar[sl][0][0], ar[sl][0][1], ar[sl][0][2], ar[sl][0][3], ar[sl][1][0], ar[sl][1][1], ar[sl][1][2], ar[sl][1][3]};
+            float sum[4], dif[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { sum[s] = y[2 * s] + y[2 * s + 1]; dif[s] = y[2 * s] - y[2 * s + 1]; }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s], V[0][s], acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(sum[s], V[1][s], acc[1][i], 0, 0, 0);
+                acc[2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dif[s], V[2][s], acc[2][i], 0, 0, 0);
+                acc[3][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s + 1], V[3][s], acc[3][i], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // partial slab of this slice: OUT[slice][point][m][n]; lane holds rows 4g..4g+3 of column r16
+    const int n = n0 + 16 * wave + r16;
+    if (n < prm.Kp) {
+        float* out = OUT + (size_t)slice * 4 * prm.M * prm.Kp;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 16 * i + 4 * g + r;
+                    if (m < prm.M) out[((size_t)p * prm.M + m) * prm.Kp + n] = acc[p][i][r];
+                }
+    }
+#endif
+}
+
+// dW[co][ci][r][kw] from the slabs [slice][point][co][r * Cpad + ci]: 32 elements x 8 slice groups per block (group g adds
+// slices g, g+8, ... in order, then the groups are added in order -- fixed order, bitwise reproducible), then G^T.
+__global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int M,
+                                                             int Cin, int R, int Cpad, int slices) {
+    __shared__ float part[8][4][32];
+    const size_t plane = (size_t)M * R * Cpad;              // one point of one slice
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (size_t j0 = (size_t)blockIdx.x * 32; j0 < plane; j0 += (size_t)gridDim.x * 32) {
+        const size_t j = j0 + e;
+        const int ci = (int)(j % Cpad);
+        const bool live = j < plane && ci < Cin;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live)
+            for (int k = grp; k < slices; k += 8)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) s[p] += slabs[((size_t)k * 4 + p) * plane + j];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) part[grp][p][e] = s[p];
+        __syncthreads();
+        if (grp == 0 && live) {
+            float Mv[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float t = part[0][p][e];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) t += part[q][p][e];
+                Mv[p] = t;
+            }
+            const size_t rr = j / Cpad;
+            const int r = (int)(rr % R), co = (int)(rr / R);
+            float* o = dw + (((size_t)co * Cin + ci) * R + r) * 3;
+            const float h = 0.5f * (Mv[1] + Mv[2]);
+            o[0] = Mv[0] + h;
+            o[1] = 0.5f * (Mv[1] - Mv[2]);
+            o[2] = h - Mv[3];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+struct WgradWinoPlan {
+    int tm, tiles_m, tiles_n, slices, chunks_per_slice, Cpad, Kp;
+};
+
+static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
+    WgradWinoPlan pl;
+    const int M = d->Cout;
+    pl.Cpad = (d->Cin + 15) / 16 * 16;
+    pl.Kp = 3 * d->kT * pl.Cpad;
+    const int p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128;
+    pl.tm = p9 <= p8 ? 9 : 8;
+    const int bm = 16 * pl.tm;
+    pl.tiles_m = (M + bm - 1) / bm;
+    pl.tiles_n = (pl.Kp + 63) / 64;
+    const long chunks = (long)d->N * d->Ti * d->Hi * d->Wi / 32;
+    const long tiles = (long)pl.tiles_m * pl.tiles_n, resident = 512;       // 2 workgroups per CU
+    // whole rounds of resident workgroups, at least 24 chunks (768 voxels) per slice
+    long rounds = 1;
+    if (const char* e = getenv("ZSV_WGRAD_WINO_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
+    long sl = rounds * resident / tiles;
+    if (sl > chunks / 24) sl = chunks / 24;
+    if (const char* e = getenv("ZSV_WGRAD_WINO_SLICES")) sl = atol(e);
+    if (sl < 1) sl = 1;
+    if (sl > chunks) sl = chunks;
+    pl.chunks_per_slice = (int)((chunks + sl - 1) / sl);
+    pl.slices = (int)((chunks + pl.chunks_per_slice - 1) / pl.chunks_per_slice);
+    return pl;
+}
+
+bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* dy) {
+    if (getenv("ZSV_NO_WINO") || getenv("ZSV_NO_WGRAD_WINO")) return false;
+    if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
+        d->pH != 1 || d->pW != 1)
+        return false;
+    if (d->Wi % 4 != 0 || d->Cin < 16) return false;
+    const long S = (long)d->Ti * d->Hi * d->Wi;
+    if (S % 32 != 0) return false;
+    if ((long)d->N * d->Cin * S >= (1L << 29) || (long)d->N * d->Cout * S >= (1L << 29)) return false;   // int byte offsets
+    const int M = d->Cout, p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128, pm = p9 <= p8 ? p9 : p8;
+    if (pm * 10 > M * 13) return false;                          // row padding above 30 %: the plain kernel's tiles fit better
+    if ((long)d->N * S < 32768) return false;                    // too few voxels to give the workgroups useful slices
+    if (x != nullptr && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return false;
+    return true;
+}
+
+static size_t ww_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t wgrad_wino_workspace_bytes(const zsv_conv_desc* d) {
+    const WgradWinoPlan pl = wgrad_wino_plan(d);
+    const size_t S = (size_t)d->Ti * d->Hi * d->Wi;
+    return ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)) + S * sizeof(unsigned);
+}
+
+template <int TM>
+static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t stream, const float* x, const float* dy,
+                             const unsigned* vm, float* out) {
+    constexpr int LDS_BYTES = 2 * (((16 * TM * 9 + 63) / 64 + 11 + 1) * 1024);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    hipLaunchKernelGGL(conv_wgrad_wino_kernel<TM>, dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
+                       dy, vm, out);
+    return launch_status();
+}
+
+int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+               hipStream_t stream) {
+    const WgradWinoPlan pl = wgrad_wino_plan(d);
+    if (!workspace || workspace_bytes < wgrad_wino_workspace_bytes(d)) return ZSV_E_WORKSPACE;
+    WgradWinoParams p;
+    p.M = d->Cout; p.Cin = d->Cin; p.Cpad = pl.Cpad; p.R = 3 * d->kT; p.Kp = pl.Kp;
+    p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.kT = d->kT;
+    p.chunks_total = (int)((long)d->N * p.S / 32);
+    p.chunks_per_slice = pl.chunks_per_slice;
+    p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.S);
+    p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
+    p.vm_bytes = 4u * (unsigned)p.S;
+    p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
+    float* slabs = (float*)workspace;
+    unsigned* vm = (unsigned*)((char*)workspace + ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)));
+    int st = wgrad_vmask(d, vm, stream);
+    if (st) return st;
+    st = pl.tm == 9 ? wgrad_wino_launch<9>(p, pl.slices, stream, x, dy, vm, slabs)
+                    : wgrad_wino_launch<8>(p, pl.slices, stream, x, dy, vm, slabs);
+    if (st) return st;
+    const long n = (long)d->Cout * p.R * pl.Cpad;
+    long blocks = (n + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_wino_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)slabs, dw, d->Cout,
+                       d->Cin, p.R, pl.Cpad, pl.slices);
+    return launch_status();
+}
+
+}  // namespace zsv
