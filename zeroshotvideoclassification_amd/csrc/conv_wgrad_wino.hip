@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x % prm.tiles_mn, slice = blockIdx.x / prm.tiles_mn;
+    // the column / row tiles of one slice read the same dY (X) rows: consecutive logical ids share an XCD (one L2)
+    const int lid = xcd_tile(gridDim.x, blockIdx.x);
+    const int tile = lid % prm.tiles_mn, slice = lid / prm.tiles_mn;
     const int m0 = (tile % prm.tiles_m) * BM, n0 = (tile / prm.tiles_m) * 64;
     const int c0 = slice * prm.chunks_per_slice;
     const int nq = min(prm.chunks_per_slice, prm.chunks_total - c0);
