@@ -251,7 +251,7 @@ def main():
             # the kernel computes the kw taps in Winograd F(2,3) form: 4 multiplies per output pair instead of 6,
             # so the matrix pipe executes 2/3 of the algorithmic FLOPs (counter-checked: profiles/r01_s1_mfma_busy.json)
             executed = flops * 2.0 / 3.0 / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "zsv::conv_wino_kernel<3, 12> = Conv3d(64,144,(1,3,3)) forward @16x56x56 "
+            out["roofline"] = {"kernel": "zsv::conv_wino_kernel<3, 12, true> = Conv3d(64,144,(1,3,3)) forward @16x56x56 "
                                          "(fp32 Winograd F(2,3) along W + its weight-transform launch), 4 launches/step",
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
