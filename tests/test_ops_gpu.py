@@ -622,3 +622,38 @@ def test_conv3d_wgrad_winograd_path(case, monkeypatch):
     b = run()
     close(b, ref, what=f"{name} wgrad (plain)")
     assert not torch.equal(a, b), "the two paths should not be the same kernel"
+
+
+FULL_SIZE_LAYERS = [
+    # BASELINE.json configs[1] / configs[3] geometries at the benchmark's 22 clips: name, Cin, Cout, kernel, padding, (T,H,W)
+    ("S1_spatial_64_144", 64, 144, (1, 3, 3), (0, 1, 1), (16, 56, 56)),
+    ("T1_temporal_144_64", 144, 64, (3, 1, 1), (1, 0, 0), (16, 56, 56)),
+    ("S4_spatial_128_288", 128, 288, (1, 3, 3), (0, 1, 1), (8, 28, 28)),
+    ("S7_spatial_256_576", 256, 576, (1, 3, 3), (0, 1, 1), (4, 14, 14)),
+    ("C2_c3d_64_128", 64, 128, (3, 3, 3), (1, 1, 1), (16, 56, 56)),
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_LAYERS, ids=[c[0] for c in FULL_SIZE_LAYERS])
+def test_full_size_adjoint_identities(case):
+    """Size-independent property at the benchmark's full size (N = 22), where a CPU fp64 convolution is
+    too slow to be the checker: forward, input gradient and weight gradient are the three faces of one
+    trilinear form, so <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(x, g)> -- checked with fp64 dot
+    products; plus the forward against torch CPU fp64 on one clip of the batch."""
+    name, cin, cout, k, p, (t, h, w) = case
+    n = 22
+    g = torch.Generator(device=DEV).manual_seed(len(name))
+    x = torch.randn(n, cin, t, h, w, device=DEV, generator=g).requires_grad_()
+    wt = (torch.randn(cout, cin, *k, device=DEV, generator=g) / np.sqrt(cin * np.prod(k))).requires_grad_()
+    gy = torch.randn(n, cout, t, h, w, device=DEV, generator=g)
+    y = ops.conv3d(x, wt, None, 1, p)
+    y.backward(gy)
+    a = (y.detach().double() * gy.double()).sum().item()
+    b = (x.detach().double() * x.grad.double()).sum().item()
+    c = (wt.detach().double() * wt.grad.double()).sum().item()
+    scale = (y.detach().double().norm() * gy.double().norm()).item()
+    assert abs(a - b) <= 2e-6 * scale, f"{name}: <y,g>={a!r} vs <x,dx>={b!r} (scale {scale:.3e})"
+    assert abs(a - c) <= 2e-6 * scale, f"{name}: <y,g>={a!r} vs <w,dw>={c!r} (scale {scale:.3e})"
+    i = n - 1                                               # last clip: the tail tiles
+    ref = F.conv3d(x.detach()[i:i + 1].cpu().double(), wt.detach().cpu().double(), padding=p)
+    close(y.detach()[i:i + 1], ref, what=f"{name} forward, clip {i}")
