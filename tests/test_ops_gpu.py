@@ -595,6 +595,10 @@ WGRAD_WINO_CASES = [
     ("m230_cin45", 6, 45, (8, 28, 28), 230, 1),              # two 128-row tiles (ragged), channel padding, ragged column tile
     ("c3d_333", 2, 32, (8, 32, 64), 128, 3),                 # 9 row taps
     ("two_frames_333", 8, 16, (2, 32, 64), 120, 3),          # every voxel touches a temporal border
+    ("layer3_14x14", 22, 32, (4, 14, 14), 144, 1),           # W % 4 = 2 (unaligned X pieces), S = 784: partial last chunk
+    ("w_10_odd_chunks", 30, 16, (3, 20, 10), 128, 3),        # S = 600 = 18.75 chunks
+    ("partial_chunk_aligned_w", 24, 16, (3, 20, 12), 128, 1),  # S = 720 = 22.5 chunks, W % 4 = 0
+    ("unaligned_w_whole_chunks", 28, 16, (4, 16, 10), 128, 1), # S = 640 = 20 chunks, W % 4 = 2
 ]
 
 

@@ -21,7 +21,9 @@
 //     (voxels p-4 .. p+39 of the shifted row) -- pitches of 36 / 44 banks make the ds_read_b128 fragments conflict-free.
 //   * Borders: the per-voxel tap-validity words of conv_wgrad_dma.hip (wgrad_vmask_kernel) are DMA'd with the operands;
 //     d0 / (d1, d2) / d3 of a pair are zeroed by the bits (r, kw=0) / (r, kw=1) of its first and (r, kw=2) of its second
-//     voxel.  Rows read past a row / plane / clip pick up neighbouring values, which the same bits discard.
+//     voxel.  Rows read past a row / plane / clip pick up neighbouring values, which the same bits discard.  A clip whose
+//     voxel count is not a multiple of 32 ends with a partial chunk: its dY pieces past the clip are DMA'd as zeros and the
+//     mask words past the clip read as zero.  X pieces need not be 16-byte aligned (W % 4 != 0), only dword aligned.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -37,12 +39,13 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 struct WgradWinoParams {
     int M, Cin, Cpad, R, Kp;          // Kp = R * Cpad columns, row-tap major
     int S, HW, W, kT;
-    int chunks_total, chunks_per_slice;      // 32-voxel chunks
+    int chunks_total, chunks_per_slice, cpc; // 32-voxel chunks; cpc = chunks per clip (the last one may be partly past the clip)
     unsigned x_bytes, dy_bytes, vm_bytes;
     int tiles_m, tiles_mn;
 };
 
-template <int TM>
+// EDGE = the clip's voxel count is not a multiple of 32 or W is not a multiple of 4 (partial last chunk, unaligned X pieces)
+template <int TM, bool EDGE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams prm, const float* __restrict__ X,
                                                                  const float* __restrict__ DY,
                                                                  const unsigned* __restrict__ VM, float* __restrict__ OUT) {
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
     const int m0 = (tile % prm.tiles_m) * BM, n0 = (tile / prm.tiles_m) * 64;
     const int c0 = slice * prm.chunks_per_slice;
     const int nq = min(prm.chunks_per_slice, prm.chunks_total - c0);
-    const int cpc = prm.S / 32;                             // chunks per clip
+    const int cpc = prm.cpc;
     int n_img = c0 / cpc;
     int p_local = (c0 - n_img * cpc) * 32;
 
@@ -75,13 +78,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
     const __amdgpu_buffer_rsrc_t rs_vm = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(VM), 0, prm.vm_bytes, 0x00020000);
 
     // ---- DMA assignment: piece id = 64 * instruction + lane -> (row, 16-byte piece of the row) ------------------
-    int a_off[NA];                      // byte offset inside clip 0 at p_local = 0, or -1: reads as zeros
+    int a_off[NA], a_vox[NA];           // byte offset inside clip 0 at p_local = 0 (or -1: reads as zeros); first voxel of the piece
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int id = 64 * (wave + 4 * k) + lane;
         const int row = id / 9, pc = id - row * 9;
         const bool ok = row < BM && m0 + row < prm.M && pc < 8;
         a_off[k] = ok ? 4 * ((m0 + row) * prm.S + 4 * pc) : -1;
+        a_vox[k] = 4 * pc;
     }
     int b_off[NB];
     bool b_ok[NB];
@@ -97,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
         b_off[k] = 4 * (ci * prm.S + delta + 4 * pc - 4);          // may be negative at p_local = 0 (then out of range)
     }
 
+    // A 16-byte X piece that straddles the first float of the tensor (only with W % 4 != 0: clip 0, channel 0, first chunk)
+    // cannot be fetched whole: it is DMA'd as zeros and its in-range floats are patched in after the wait.
+    int patch_off[NB];
     auto issue = [&](int buf) {
         unsigned char* base = lds + buf * STAGE;
         const int a_chunk = 4 * (n_img * prm.M * prm.S + p_local);
@@ -105,11 +112,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
         for (int k = 0; k < NA; ++k)
             if (wave + 4 * k < NA_TOT)                              // wave-uniform
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_ptr_t)(base + 1024 * (wave + 4 * k)), 16,
-                                                         (int)(a_off[k] >= 0 ? (unsigned)(a_off[k] + a_chunk) : OOB), 0, 0, 0);
+                                                         (int)((a_off[k] >= 0 && (!EDGE || p_local + a_vox[k] < prm.S)) ? (unsigned)(a_off[k] + a_chunk) : OOB), 0, 0, 0);   // (dY past the clip = 0)
 #pragma unroll
         for (int k = 0; k < NB; ++k)
             if (wave + 4 * k < NB_TOT) {
                 const int off = b_off[k] + b_chunk;                 // negative = before the tensor: reads as zeros
+                if constexpr (EDGE) patch_off[k] = (b_ok[k] && off < 0 && off > -16) ? off : 0;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(base + A_BYTES + 1024 * (wave + 4 * k)), 16,
                                                          (int)((b_ok[k] && off >= 0) ? (unsigned)off : OOB), 0, 0, 0);
             }
@@ -117,7 +125,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_vm, (lds_ptr_t)(base + VM_AT), 16,
                                                      (int)(lane < 8 ? (unsigned)(4 * (p_local + 4 * lane)) : OOB), 0, 0, 0);
         p_local += 32;
-        if (p_local == prm.S) { p_local = 0; ++n_img; }
+        if (p_local >= prm.S) { p_local = 0; ++n_img; }
+    };
+
+    auto patch_edges = [&](int buf) {                   // after the chunk's DMAs have landed, before the barrier
+        if constexpr (!EDGE) return;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) any = any || (wave + 4 * k < NB_TOT && patch_off[k] != 0);
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (wave + 4 * k >= NB_TOT || patch_off[k] == 0) continue;
+            float* dst = (float*)(lds + buf * STAGE + A_BYTES + 1024 * (wave + 4 * k) + lane * 16);
+            for (int e = 0; e < 4; ++e)
+                if (patch_off[k] + 4 * e >= 0) dst[e] = X[(patch_off[k] + 4 * e) / 4];
+        }
     };
 
     f32x4 acc[4][TM];
@@ -135,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
 
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    patch_edges(0);
     __syncthreads();
     for (int ch = 0; ch < nq; ++ch) {
         const int cur = ch & 1;
@@ -181,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ch + 1 < nq) patch_edges(cur ^ 1);
         __syncthreads();
     }
 
@@ -256,13 +281,23 @@ static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
     const int bm = 16 * pl.tm;
     pl.tiles_m = (M + bm - 1) / bm;
     pl.tiles_n = (pl.Kp + 63) / 64;
-    const long chunks = (long)d->N * d->Ti * d->Hi * d->Wi / 32;
+    const long chunks = (long)d->N * (((long)d->Ti * d->Hi * d->Wi + 31) / 32);
     const long tiles = (long)pl.tiles_m * pl.tiles_n, resident = 512;       // 2 workgroups per CU
-    // whole rounds of resident workgroups, at least 24 chunks (768 voxels) per slice
-    long rounds = 1;
-    if (const char* e = getenv("ZSV_WGRAD_WINO_ROUNDS")) rounds = atol(e) > 0 ? atol(e) : 1;
-    long sl = rounds * resident / tiles;
-    if (sl > chunks / 24) sl = chunks / 24;
+    // slices: the count that minimises (MFMA time / fill of the rounds of resident workgroups) + (slab write + read),
+    // at least 24 chunks (768 voxels) per slice
+    const double voxels = (double)chunks * 32.0;
+    const double t_mfma = 4.0 * (double)(pl.tiles_m * bm) * (double)(pl.tiles_n * 64) * voxels / 1.1e14;
+    const double t_slice = 2.0 * 4.0 * (double)M * pl.Kp * sizeof(float) / 6.0e12;
+    long max_sl = chunks / 24;
+    if (max_sl < 1) max_sl = 1;
+    if (max_sl > 4096) max_sl = 4096;
+    long sl = 1;
+    double best = 1e300;
+    for (long c = 1; c <= max_sl; ++c) {
+        const long wgs = tiles * c, rounds = (wgs + resident - 1) / resident;
+        const double cost = t_mfma * (double)(rounds * resident) / (double)wgs + t_slice * (double)c;
+        if (cost < best * 0.999) { best = cost; sl = c; }
+    }
     if (const char* e = getenv("ZSV_WGRAD_WINO_SLICES")) sl = atol(e);
     if (sl < 1) sl = 1;
     if (sl > chunks) sl = chunks;
@@ -276,13 +311,13 @@ bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* 
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
         d->pH != 1 || d->pW != 1)
         return false;
-    if (d->Wi % 4 != 0 || d->Cin < 16) return false;
+    if (d->Wi % 2 != 0 || d->Cin < 16) return false;
     const long S = (long)d->Ti * d->Hi * d->Wi;
-    if (S % 32 != 0) return false;
+    if (S % 4 != 0) return false;                                // a 16-byte dY piece never straddles the end of a clip
     if ((long)d->N * d->Cin * S >= (1L << 29) || (long)d->N * d->Cout * S >= (1L << 29)) return false;   // int byte offsets
     const int M = d->Cout, p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128, pm = p9 <= p8 ? p9 : p8;
     if (pm * 10 > M * 13) return false;                          // row padding above 30 %: the plain kernel's tiles fit better
-    if ((long)d->N * S < 32768) return false;                    // too few voxels to give the workgroups useful slices
+    if ((long)d->N * S < 16384) return false;                    // too few voxels to give the workgroups useful slices
     if (x != nullptr && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return false;
     return true;
 }
@@ -295,14 +330,14 @@ size_t wgrad_wino_workspace_bytes(const zsv_conv_desc* d) {
     return ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)) + S * sizeof(unsigned);
 }
 
-template <int TM>
+template <int TM, bool EDGE>
 static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t stream, const float* x, const float* dy,
                              const unsigned* vm, float* out) {
     constexpr int LDS_BYTES = 2 * (((16 * TM * 9 + 63) / 64 + 11 + 1) * 1024);
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM>,
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, EDGE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    hipLaunchKernelGGL(conv_wgrad_wino_kernel<TM>, dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
+    hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, vm, out);
     return launch_status();
 }
@@ -314,7 +349,8 @@ int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* d
     WgradWinoParams p;
     p.M = d->Cout; p.Cin = d->Cin; p.Cpad = pl.Cpad; p.R = 3 * d->kT; p.Kp = pl.Kp;
     p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.kT = d->kT;
-    p.chunks_total = (int)((long)d->N * p.S / 32);
+    p.cpc = (p.S + 31) / 32;
+    p.chunks_total = d->N * p.cpc;
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.S);
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
@@ -324,8 +360,13 @@ int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* d
     unsigned* vm = (unsigned*)((char*)workspace + ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)));
     int st = wgrad_vmask(d, vm, stream);
     if (st) return st;
-    st = pl.tm == 9 ? wgrad_wino_launch<9>(p, pl.slices, stream, x, dy, vm, slabs)
-                    : wgrad_wino_launch<8>(p, pl.slices, stream, x, dy, vm, slabs);
+    const bool edge = p.S % 32 != 0 || d->Wi % 4 != 0;
+    if (pl.tm == 9)
+        st = edge ? wgrad_wino_launch<9, true>(p, pl.slices, stream, x, dy, vm, slabs)
+                  : wgrad_wino_launch<9, false>(p, pl.slices, stream, x, dy, vm, slabs);
+    else
+        st = edge ? wgrad_wino_launch<8, true>(p, pl.slices, stream, x, dy, vm, slabs)
+                  : wgrad_wino_launch<8, false>(p, pl.slices, stream, x, dy, vm, slabs);
     if (st) return st;
     const long n = (long)d->Cout * p.R * pl.Cpad;
     long blocks = (n + 31) / 32;
