@@ -597,6 +597,9 @@ WGRAD_WINO_CASES = [
     ("two_frames_333", 8, 16, (2, 32, 64), 120, 3),          # every voxel touches a temporal border
     ("layer3_14x14", 22, 32, (4, 14, 14), 144, 1),           # W % 4 = 2 (unaligned X pieces), S = 784: partial last chunk
     ("w_10_odd_chunks", 30, 16, (3, 20, 10), 128, 3),        # S = 600 = 18.75 chunks
+    ("r3d_layer1_like_64_rows", 2, 64, (8, 32, 64), 64, 3),    # 64-row tile, two column blocks per wave
+    ("m56_ragged_columns", 4, 24, (4, 32, 40), 56, 1),          # 64-row tile, 96 of 128 columns, ragged rows
+    ("m64_14x14", 22, 32, (4, 14, 14), 64, 1),                  # 64-row tile with the edge handling
     ("partial_chunk_aligned_w", 24, 16, (3, 20, 12), 128, 1),  # S = 720 = 22.5 chunks, W % 4 = 0
     ("unaligned_w_whole_chunks", 28, 16, (4, 16, 10), 128, 1), # S = 640 = 20 chunks, W % 4 = 2
 ]

@@ -47,6 +47,10 @@ SHAPES = {
     "C4a": (256, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14),
     "C4b": (512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14),
     "C5": (512, 512, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, 7, 7),
+    # R3D-18 / MC3-18 (resnet.py:23-30): 3x3x3 stride 1 -- not part of --shapes all
+    "R1": (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 16, 56, 56),
+    "R2": (128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), 8, 28, 28),
+    "R3": (256, 256, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, 14, 14),
 }
 
 
@@ -60,7 +64,7 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda")
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    names = [n for n in SHAPES if not n.startswith("C")] if args.shapes == "all" else args.shapes.split(",")
+    names = [n for n in SHAPES if n[0] not in "CR"] if args.shapes == "all" else args.shapes.split(",")
     tot = {}
     for name in names:
         cin, cout, k, s, p, t, h, w = SHAPES[name]

@@ -10,7 +10,8 @@
 // 4 multiplies per pair and (co, ci, r) instead of 6: 1.5x fewer MFMAs than conv_wgrad_dma.hip, still fp32 in / fp32
 // accumulate (V is the same transform as the forward's, conv_wino.hip).
 //
-// GEMM per point: rows = 16*TM output channels, columns = 64 (r, ci) pairs per workgroup (one 16-column block per wave),
+// GEMM per point: rows = 16*TM output channels, columns = 64*TN (r, ci) pairs per workgroup (TN 16-column blocks per wave:
+// 1 for the 128 / 144-row tiles, 2 for the 64-row tile of the 64-channel layers),
 // reduction over voxel pairs, cut into slices (one round of workgroups covers the problem); every slice writes its
 // partial [point][co][(r, ci)] slab and wgrad_wino_sum_kernel adds the slabs in a fixed order and applies the output
 // transform: bitwise reproducible, no float atomics.
@@ -45,7 +46,7 @@ struct WgradWinoParams {
 };
 
 // EDGE = the clip's voxel count is not a multiple of 32 or W is not a multiple of 4 (partial last chunk, unaligned X pieces)
-template <int TM, bool EDGE>
+template <int TM, int TN, bool EDGE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams prm, const float* __restrict__ X,
                                                                  const float* __restrict__ DY,
                                                                  const unsigned* __restrict__ VM, float* __restrict__ OUT) {
@@ -53,8 +54,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
     constexpr int BM = 16 * TM;
     constexpr int LDA = 36, LDB = 44;                       // floats per LDS row (9 / 11 pieces of 16 bytes)
     constexpr int NA_TOT = (BM * 9 + 63) / 64;              // 1-KiB DMA instructions per stage: dY rows
-    constexpr int NB_TOT = 11;                              //                                    X rows (64 x 11 pieces)
-    constexpr int NA = (NA_TOT + 3) / 4, NB = 3;            // per wave
+    constexpr int BN = 64 * TN;                             // columns per workgroup
+    constexpr int NB_TOT = 11 * TN;                         //                                    X rows (BN x 11 pieces)
+    constexpr int NA = (NA_TOT + 3) / 4, NB = (NB_TOT + 3) / 4;   // per wave
     constexpr int A_BYTES = NA_TOT * 1024, B_BYTES = NB_TOT * 1024;
     constexpr int VM_AT = A_BYTES + B_BYTES;
     constexpr int STAGE = VM_AT + 1024;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
     // the column / row tiles of one slice read the same dY (X) rows: consecutive logical ids share an XCD (one L2)
     const int lid = xcd_tile(gridDim.x, blockIdx.x);
     const int tile = lid % prm.tiles_mn, slice = lid / prm.tiles_mn;
-    const int m0 = (tile % prm.tiles_m) * BM, n0 = (tile / prm.tiles_m) * 64;
+    const int m0 = (tile % prm.tiles_m) * BM, n0 = (tile / prm.tiles_m) * BN;
     const int c0 = slice * prm.chunks_per_slice;
     const int nq = min(prm.chunks_per_slice, prm.chunks_total - c0);
     const int cpc = prm.cpc;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
         const int r = n / prm.Cpad, ci = n - r * prm.Cpad;
         const int kt = r / 3, kh = r - 3 * kt;
         const int delta = (kt - prm.kT / 2) * prm.HW + (kh - 1) * prm.W;
-        b_ok[k] = row < 64 && n < prm.Kp && ci < prm.Cin;
+        b_ok[k] = row < BN && n < prm.Kp && ci < prm.Cin;
         b_off[k] = 4 * (ci * prm.S + delta + 4 * pc - 4);          // may be negative at p_local = 0 (then out of range)
     }
 
@@ -143,17 +145,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
         }
     };
 
-    f32x4 acc[4][TM];
+    f32x4 acc[4][TM][TN];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, r16 = lane & 15;
-    const int r_tap = min((n0 + 16 * wave) / prm.Cpad, 8);           // row tap of this wave's 16 columns (Cpad % 16 == 0)
-    const unsigned bit0 = 1u << (3 * r_tap), bit1 = 2u << (3 * r_tap), bit2 = 4u << (3 * r_tap);
+    unsigned bit0[TN], bit1[TN], bit2[TN];                            // row tap of each of this wave's 16-column blocks (Cpad % 16 == 0)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r_tap = min((n0 + 16 * (wave * TN + j)) / prm.Cpad, 8);
+        bit0[j] = 1u << (3 * r_tap); bit1[j] = 2u << (3 * r_tap); bit2[j] = 4u << (3 * r_tap);
+    }
     const int a_frag = (r16 * LDA + 8 * g) * 4;                       // bytes inside the A image (+ 16 * LDA * 4 per block)
-    const int b_frag = A_BYTES + ((16 * wave + r16) * LDB + 8 * g + 4) * 4;
+    const int b_frag = A_BYTES + ((16 * wave * TN + r16) * LDB + 8 * g + 4) * 4;      // (+ 16 * LDB * 4 per column block)
     const int v_frag = VM_AT + g * 32;
 
     issue(0);
@@ -166,20 +174,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
         const unsigned char* st = lds + cur * STAGE;
         // this lane's 8 voxels (4 pairs) of its X row, their halo and their mask words
         const u32x4w vm0 = *reinterpret_cast<const u32x4w*>(st + v_frag), vm1 = *reinterpret_cast<const u32x4w*>(st + v_frag + 16);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(st + b_frag), b1 = *reinterpret_cast<const f32x4*>(st + b_frag + 16);
-        const float bl = *reinterpret_cast<const float*>(st + b_frag - 4), br = *reinterpret_cast<const float*>(st + b_frag + 32);
         f32x4 ar[2][2];
         ar[0][0] = *reinterpret_cast<const f32x4*>(st + a_frag);
         ar[0][1] = *reinterpret_cast<const f32x4*>(st + a_frag + 16);
-        const float xv[10] = {bl, b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], br};
         const unsigned mw[8] = {vm0[0], vm0[1], vm0[2], vm0[3], vm1[0], vm1[1], vm1[2], vm1[3]};
-        float V[4][4];
+        float V[TN][4][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const unsigned ma = mw[2 * s], mb = mw[2 * s + 1];
-            const float d0 = (ma & bit0) ? xv[2 * s] : 0.f, d1 = (ma & bit1) ? xv[2 * s + 1] : 0.f,
-                        d2 = (ma & bit1) ? xv[2 * s + 2] : 0.f, d3 = (mb & bit2) ? xv[2 * s + 3] : 0.f;
-            V[0][s] = d0 - d2; V[1][s] = d1 + d2; V[2][s] = d2 - d1; V[3][s] = d1 - d3;
+        for (int j = 0; j < TN; ++j) {
+            const unsigned char* bp = st + b_frag + j * 16 * LDB * 4;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 16);
+            const float bl = *reinterpret_cast<const float*>(bp - 4), br = *reinterpret_cast<const float*>(bp + 32);
+            const float xv[10] = {bl, b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], br};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned ma = mw[2 * s], mb = mw[2 * s + 1];
+                const float d0 = (ma & bit0[j]) ? xv[2 * s] : 0.f, d1 = (ma & bit1[j]) ? xv[2 * s + 1] : 0.f,
+                            d2 = (ma & bit1[j]) ? xv[2 * s + 2] : 0.f, d3 = (mb & bit2[j]) ? xv[2 * s + 3] : 0.f;
+                V[j][0][s] = d0 - d2; V[j][1][s] = d1 + d2; V[j][2][s] = d2 - d1; V[j][3][s] = d1 - d3;
+            }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -195,12 +207,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s], V[0][s], acc[0][i], 0, 0, 0);
-                acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(sum[s], V[1][s], acc[1][i], 0, 0, 0);
-                acc[2][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dif[s], V[2][s], acc[2][i], 0, 0, 0);
-                acc[3][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s + 1], V[3][s], acc[3][i], 0, 0, 0);
-            }
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s], V[j][0][s], acc[0][i][j], 0, 0, 0);
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(sum[s], V[j][1][s], acc[1][i][j], 0, 0, 0);
+                    acc[2][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(dif[s], V[j][2][s], acc[2][i][j], 0, 0, 0);
+                    acc[3][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[2 * s + 1], V[j][3][s], acc[3][i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -210,9 +224,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
     }
 
     // partial slab of this slice: OUT[slice][point][m][n]; lane holds rows 4g..4g+3 of column r16
-    const int n = n0 + 16 * wave + r16;
-    if (n < prm.Kp) {
-        float* out = OUT + (size_t)slice * 4 * prm.M * prm.Kp;
+    float* out = OUT + (size_t)slice * 4 * prm.M * prm.Kp;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + 16 * (wave * TN + j) + r16;
+        if (n >= prm.Kp) continue;
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_wino_kernel(WgradWinoParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + 16 * i + 4 * g + r;
-                    if (m < prm.M) out[((size_t)p * prm.M + m) * prm.Kp + n] = acc[p][i][r];
+                    if (m < prm.M) out[((size_t)p * prm.M + m) * prm.Kp + n] = acc[p][i][j][r];
                 }
     }
 #endif
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float* __rest
 
 // ---- host side -----------------------------------------------------------------------------------
 struct WgradWinoPlan {
-    int tm, tiles_m, tiles_n, slices, chunks_per_slice, Cpad, Kp;
+    int tm, tn, tiles_m, tiles_n, slices, chunks_per_slice, Cpad, Kp;
 };
 
 static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
@@ -277,16 +293,17 @@ static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
     pl.Cpad = (d->Cin + 15) / 16 * 16;
     pl.Kp = 3 * d->kT * pl.Cpad;
     const int p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128;
-    pl.tm = p9 <= p8 ? 9 : 8;
-    const int bm = 16 * pl.tm;
+    pl.tm = M <= 64 ? 4 : (p9 <= p8 ? 9 : 8);
+    pl.tn = pl.tm == 4 ? 2 : 1;
+    const int bm = 16 * pl.tm, bn = 64 * pl.tn;
     pl.tiles_m = (M + bm - 1) / bm;
-    pl.tiles_n = (pl.Kp + 63) / 64;
+    pl.tiles_n = (pl.Kp + bn - 1) / bn;
     const long chunks = (long)d->N * (((long)d->Ti * d->Hi * d->Wi + 31) / 32);
     const long tiles = (long)pl.tiles_m * pl.tiles_n, resident = 512;       // 2 workgroups per CU
     // slices: the count that minimises (MFMA time / fill of the rounds of resident workgroups) + (slab write + read),
     // at least 24 chunks (768 voxels) per slice
     const double voxels = (double)chunks * 32.0;
-    const double t_mfma = 4.0 * (double)(pl.tiles_m * bm) * (double)(pl.tiles_n * 64) * voxels / 1.1e14;
+    const double t_mfma = 4.0 * (double)(pl.tiles_m * bm) * (double)(pl.tiles_n * bn) * voxels / 1.1e14;
     const double t_slice = 2.0 * 4.0 * (double)M * pl.Kp * sizeof(float) / 6.0e12;
     long max_sl = chunks / 24;
     if (max_sl < 1) max_sl = 1;
@@ -315,7 +332,7 @@ bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* 
     const long S = (long)d->Ti * d->Hi * d->Wi;
     if (S % 4 != 0) return false;                                // a 16-byte dY piece never straddles the end of a clip
     if ((long)d->N * d->Cin * S >= (1L << 29) || (long)d->N * d->Cout * S >= (1L << 29)) return false;   // int byte offsets
-    const int M = d->Cout, p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128, pm = p9 <= p8 ? p9 : p8;
+    const int M = d->Cout, p9 = (M + 143) / 144 * 144, p8 = (M + 127) / 128 * 128, pm = M <= 64 ? 64 : (p9 <= p8 ? p9 : p8);
     if (pm * 10 > M * 13) return false;                          // row padding above 30 %: the plain kernel's tiles fit better
     if ((long)d->N * S < 16384) return false;                    // too few voxels to give the workgroups useful slices
     if (x != nullptr && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) != 0) return false;
@@ -330,14 +347,14 @@ size_t wgrad_wino_workspace_bytes(const zsv_conv_desc* d) {
     return ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)) + S * sizeof(unsigned);
 }
 
-template <int TM, bool EDGE>
+template <int TM, int TN, bool EDGE>
 static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t stream, const float* x, const float* dy,
                              const unsigned* vm, float* out) {
-    constexpr int LDS_BYTES = 2 * (((16 * TM * 9 + 63) / 64 + 11 + 1) * 1024);
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, EDGE>,
+    constexpr int LDS_BYTES = 2 * (((16 * TM * 9 + 63) / 64 + 11 * TN + 1) * 1024);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, TN, EDGE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
+    hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, TN, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, vm, out);
     return launch_status();
 }
@@ -362,11 +379,14 @@ int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* d
     if (st) return st;
     const bool edge = p.S % 32 != 0 || d->Wi % 4 != 0;
     if (pl.tm == 9)
-        st = edge ? wgrad_wino_launch<9, true>(p, pl.slices, stream, x, dy, vm, slabs)
-                  : wgrad_wino_launch<9, false>(p, pl.slices, stream, x, dy, vm, slabs);
+        st = edge ? wgrad_wino_launch<9, 1, true>(p, pl.slices, stream, x, dy, vm, slabs)
+                  : wgrad_wino_launch<9, 1, false>(p, pl.slices, stream, x, dy, vm, slabs);
+    else if (pl.tm == 8)
+        st = edge ? wgrad_wino_launch<8, 1, true>(p, pl.slices, stream, x, dy, vm, slabs)
+                  : wgrad_wino_launch<8, 1, false>(p, pl.slices, stream, x, dy, vm, slabs);
     else
-        st = edge ? wgrad_wino_launch<8, true>(p, pl.slices, stream, x, dy, vm, slabs)
-                  : wgrad_wino_launch<8, false>(p, pl.slices, stream, x, dy, vm, slabs);
+        st = edge ? wgrad_wino_launch<4, 2, true>(p, pl.slices, stream, x, dy, vm, slabs)
+                  : wgrad_wino_launch<4, 2, false>(p, pl.slices, stream, x, dy, vm, slabs);
     if (st) return st;
     const long n = (long)d->Cout * p.R * pl.Cpad;
     long blocks = (n + 31) / 32;
