@@ -664,3 +664,41 @@ def test_full_size_adjoint_identities(case):
     i = n - 1                                               # last clip: the tail tiles
     ref = F.conv3d(x.detach()[i:i + 1].cpu().double(), wt.detach().cpu().double(), padding=p)
     close(y.detach()[i:i + 1], ref, what=f"{name} forward, clip {i}")
+
+
+@pytest.mark.parametrize("cin,cout,k,use_bias", [(256, 256, (1, 3, 3), False), (256, 256, (3, 3, 3), True), (460, 256, (1, 3, 3), False)],
+                         ids=["layer3_256_256", "r3d_layer3_333_bias_relu", "layer3_460_256"])
+def test_conv3d_winograd_split_k(cin, cout, k, use_bias, monkeypatch):
+    """Layer3-sized problems (22 clips of 4x14x14: 272 tiles, fewer than one round of workgroups) run the Winograd
+    kernel in K parts whose partial results are summed in order: forward (bias + ReLU in the sum) and input
+    gradient against torch CPU fp64 on the first and last clip and against the direct kernel on all of them."""
+    n, t, h, w = 22, 4, 14, 14
+    p = (k[0] // 2, 1, 1)
+    g = torch.Generator().manual_seed(cin + cout + k[0])
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * np.prod(k))
+    bias = torch.randn(cout, generator=g) * 0.1 if use_bias else None
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+
+    def run():
+        xg = x.to(DEV).requires_grad_()
+        y = ops.conv3d(xg, wt.to(DEV), bias.to(DEV) if use_bias else None, 1, p, relu=use_bias)
+        y.backward(dy.to(DEV))
+        return y.detach(), xg.grad
+
+    y, dx = run()
+    assert torch.equal(y, run()[0]), "bitwise reproducible"
+    for i in (0, n - 1):
+        ref = F.conv3d(x[i:i + 1].double(), wt.double(), bias.double() if use_bias else None, padding=p)
+        if use_bias:
+            ref = torch.relu(ref)
+        close(y[i:i + 1], ref, what=f"split-K winograd forward, clip {i}")
+        gm = dy[i:i + 1].double() * ((y[i:i + 1].cpu() > 0) if use_bias else 1.0)
+        close(dx[i:i + 1], torch.nn.grad.conv3d_input((1, cin, t, h, w), wt.double(), gm, padding=p),
+              what=f"split-K winograd dgrad, clip {i}")
+    monkeypatch.setenv("ZSV_NO_WINO", "1")
+    y2, dx2 = run()
+    close(y, y2.double(), rtol=5e-6, what="winograd (K parts) vs direct kernel, forward")
+    if torch.equal(y > 0, y2 > 0):
+        close(dx, dx2.double(), rtol=5e-6, what="winograd (K parts) vs direct kernel, dgrad")
+    assert not torch.equal(dx, dx2), "the two paths should not be the same kernel"

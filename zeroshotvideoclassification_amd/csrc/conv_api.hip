@@ -97,7 +97,7 @@ extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
 
 extern "C" int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y) {
     if (conv_check(d) != ZSV_OK) return 0;
-    if (wino_fwd_applicable(d)) return getenv("ZSV_NO_FUSED_STATS") ? 0 : wino_fwd_stat_tiles(d);
+    if (wino_fwd_applicable(d)) return (getenv("ZSV_NO_FUSED_STATS") || !wino_fwd_fusable(d)) ? 0 : wino_fwd_stat_tiles(d);
     IgemmParams p;
     fwd_params(p, d, 0);
     return igemm_tap_stat_tiles(p, y);
@@ -111,7 +111,7 @@ extern "C" int zsv_conv3d_fwd(const zsv_conv_desc* d, const float* x, const floa
 // y = act(conv + bias + residual) in one pass: tap kernel without split-K
 extern "C" int32_t zsv_conv3d_fwd_add_supported(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
-    if (wino_fwd_applicable(d)) return 1;
+    if (wino_fwd_applicable(d)) return wino_fwd_fusable(d) ? 1 : 0;
     IgemmParams p;
     fwd_params(p, d, 0);
     return (igemm_tap_applicable(p) && igemm_tap_ksplit(p) == 1) ? 1 : 0;
@@ -203,7 +203,7 @@ extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
 // dx = dgrad + add in one pass: stride 1 (one residue class), tap kernel, no split-K
 extern "C" int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK || d->sT != 1 || d->sH != 1 || d->sW != 1) return 0;
-    if (wino_dgrad_applicable(d)) return 1;
+    if (wino_dgrad_applicable(d)) return wino_dgrad_fusable(d) ? 1 : 0;
     IgemmParams p;
     if (!dgrad_class_params(p, d, 0, 0, 0) || p.K == 0 || !igemm_tap_applicable(p)) return 0;
     size_t wbytes;

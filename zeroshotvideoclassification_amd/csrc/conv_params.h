@@ -189,6 +189,8 @@ size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream);
 bool wino_fwd_applicable(const zsv_conv_desc* d);
+bool wino_fwd_fusable(const zsv_conv_desc* d);       // false: split-K form, no statistics / add / residual in the epilogue
+bool wino_dgrad_fusable(const zsv_conv_desc* d);
 int wino_fwd_stat_tiles(const zsv_conv_desc* d);
 size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d);
 int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,

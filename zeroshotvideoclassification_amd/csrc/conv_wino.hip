@@ -37,6 +37,8 @@ struct WinoParams {
     int P;                  // N * S
     unsigned in_bytes;
     int tiles_m, tiles_n;
+    int ksplit, chunks_per_split;   // > 1: K is cut into parts, part s writes its raw partial result to OUT + s * slab_elems
+    long slab_elems;
     const float* add;       // != nullptr: out = act(result + add + bias) (shortcut gradient / inference residual)
     const float* bias;      // != nullptr: + bias[m]
     int relu;
@@ -91,9 +93,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int lid = xcd_tile(gridDim.x, blockIdx.x);       // the K parts and row tiles of one column tile are neighbours (one L2)
+    const int split = lid % prm.ksplit, tile = lid / prm.ksplit;
     const int m0 = (tile % prm.tiles_m) * BM;
     const int n0 = (tile / prm.tiles_m) * BN;
+    if (prm.ksplit > 1) OUT += (size_t)split * prm.slab_elems;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
     const int ch_bytes = 4 * prm.S;
@@ -135,8 +139,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     }
     const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
 
-    const int nchunks = NCHUNKS > 0 ? NCHUNKS : prm.nblk * prm.R;
-    int ld_cb = 0, ld_kh = 0, ld_kt = 0;
+    const int nchunks_all = NCHUNKS > 0 ? NCHUNKS : prm.nblk * prm.R;
+    const int c_first = NCHUNKS > 0 ? 0 : split * prm.chunks_per_split;                        // this part's chunks
+    const int nchunks = NCHUNKS > 0 ? NCHUNKS : min(prm.chunks_per_split, nchunks_all - c_first);
+    int ld_cb = c_first / prm.R, ld_kt = (c_first % prm.R) / 3, ld_kh = c_first % 3;           // (R = 3 * kT)
     auto issue = [&](int chunk, int buf) {
         float* as = pool + buf * STAGE;
         float* bs = as + A_FLOATS;
@@ -209,13 +215,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         zero_d3[j] = w + 2 >= prm.W;
     }
 
-    issue(0, 0);
+    issue(c_first, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // wave 0 moves the halo values its own DMA fetched
     place_halo(0);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
         const float* as = pool + cur * STAGE;
         const float* bs = as + A_FLOATS;
         // fragments of k-step s+1 are fetched before the MFMA burst of step s (ZSV_WINO_PIPE)
@@ -329,6 +335,21 @@ static int wino_tm(int M) {
     return p48 < p64 ? 3 : 4;
 }
 
+// K parts: 1 when the tiles alone fill the two-workgroups-per-CU round, else 2..4 parts of >= 12 chunks each that do
+// (their raw partial results go to slabs, summed by splitk_reduce); 0 = too few tiles either way: the direct kernel
+static int wino_ksplit(const zsv_conv_desc* d, int M) {
+    const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
+    const int bm = 16 * wino_tm(M), C = M == d->Cout ? d->Cin : d->Cout;
+    const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256), nchunks = (long)((C + 15) / 16) * 3 * d->kT;
+    const char* e = getenv("ZSV_WINO_MIN_TILES");
+    const long min_tiles = e ? atol(e) : 512;
+    if (tiles >= min_tiles) return 1;
+    if (getenv("ZSV_WINO_NO_SPLITK")) return 0;
+    for (long ks = 2; ks <= 4; ++ks)
+        if (tiles * ks >= min_tiles && nchunks / ks >= 12) return (int)ks;
+    return 0;
+}
+
 static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (getenv("ZSV_NO_WINO")) return false;
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
@@ -337,10 +358,7 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (d->Wi % 2 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     if (P % 2 != 0 || (long)d->Cout * P >= (1L << 30) || (long)d->Cin * P >= (1L << 30)) return false;
-    const int bm = 16 * wino_tm(M);
-    const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256);
-    const char* e = getenv("ZSV_WINO_MIN_TILES");
-    return tiles >= (e ? atol(e) : 512);                 // (no split-K form)
+    return wino_ksplit(d, M) > 0;
 }
 
 // dgrad / forward of a 1x3x3 or 3x3x3 stride-1 "same" convolution with enough voxel tiles to fill the chip
@@ -352,8 +370,17 @@ static size_t wino_bytes(int M, int C, int kT) {
     const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
     return wino_align((size_t)nblk * 3 * kT * 4 * 16 * Mp * sizeof(float));
 }
-size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cin, d->Cout, d->kT); }
-size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_bytes(d->Cout, d->Cin, d->kT); }
+// transformed weights + (split-K) the parts' slabs
+static size_t wino_total_bytes(const zsv_conv_desc* d, int M, int C) {
+    const int ks = wino_ksplit(d, M);
+    const size_t out_bytes = (size_t)d->N * M * d->Ti * d->Hi * d->Wi * sizeof(float);
+    return wino_bytes(M, C, d->kT) + (ks > 1 ? (size_t)ks * out_bytes : 0);
+}
+size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_total_bytes(d, d->Cin, d->Cout); }
+size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_total_bytes(d, d->Cout, d->Cin); }
+// the epilogue extras (statistics, add, bias, ReLU) need the whole K in one workgroup
+bool wino_dgrad_fusable(const zsv_conv_desc* d) { return wino_ksplit(d, d->Cin) == 1; }
+bool wino_fwd_fusable(const zsv_conv_desc* d) { return wino_ksplit(d, d->Cout) == 1; }
 
 template <int TM, int NCHUNKS, bool X4>
 static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
@@ -361,7 +388,7 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
     constexpr int LDS_BYTES = 2 * (4 * 16 * LDA + 16 * 288 + 64) * 4;
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM, NCHUNKS, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    const long tiles = (long)p.tiles_m * p.tiles_n;
+    const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
     hipLaunchKernelGGL((conv_wino_kernel<TM, NCHUNKS, X4>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
@@ -370,8 +397,12 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
 static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
                     const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, float* out,
                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!workspace || workspace_bytes < wino_bytes(M, C, d->kT)) return ZSV_E_WORKSPACE;
+    float* const final_out = out;
+    if (!workspace || workspace_bytes < wino_total_bytes(d, M, C)) return ZSV_E_WORKSPACE;
     const int tm = wino_tm(M), bm = 16 * tm;
+    const int ks = wino_ksplit(d, M);
+    if (ks < 1) return ZSV_E_UNSUPPORTED;
+    if (ks > 1 && (add != nullptr || stat_sum != nullptr)) return ZSV_E_UNSUPPORTED;
     WinoParams p;
     p.M = M;
     p.Mp = (M + bm - 1) / bm * bm;
@@ -384,7 +415,12 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     p.tiles_m = p.Mp / bm;
     p.tiles_n = (p.P + 255) / 256;
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.ksplit = ks;
+    p.chunks_per_split = (p.nblk * p.R + ks - 1) / ks;
+    p.slab_elems = (long)d->N * M * p.S;
     float* up = (float*)workspace;
+    float* slabs = (float*)((char*)workspace + wino_bytes(M, C, d->kT));
+    if (ks > 1) { p.bias = nullptr; p.relu = 0; out = slabs; }         // bias / ReLU move to the ordered sum of the parts
     const long total = (long)p.nblk * p.R * 4 * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
@@ -392,11 +428,15 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
                        total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const bool x4 = d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_X4") == nullptr;
+    int st;
     if (tm == 3) {
-        if (x4) return p.nblk * p.R == 12 ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
-        return wino_launch<3, 0, false>(p, up, in, out, stream);
+        if (x4) st = (p.nblk * p.R == 12 && ks == 1) ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
+        else st = wino_launch<3, 0, false>(p, up, in, out, stream);
+    } else {
+        st = x4 ? wino_launch<4, 0, true>(p, up, in, out, stream) : wino_launch<4, 0, false>(p, up, in, out, stream);
     }
-    return x4 ? wino_launch<4, 0, true>(p, up, in, out, stream) : wino_launch<4, 0, false>(p, up, in, out, stream);
+    if (st || ks == 1) return st;
+    return splitk_reduce(slabs, ks, p.slab_elems, M, p.S, bias, relu, final_out, stream);
 }
 
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
