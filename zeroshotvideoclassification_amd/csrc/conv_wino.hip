@@ -278,22 +278,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     const bool stats = prm.stat_sum != nullptr;
     float* red = pool;                                   // [4 waves][BM][2] partial sums (the staging LDS is free now)
     if (stats) __syncthreads();
+    // element offset of this lane's two pairs inside row 0 of their clip (one division per pair, not per stored value;
+    // M * P < 2^30: int offsets)
+    int pair_off[2];
+    bool pair_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int v0 = n0 + 64 * wave + 2 * (16 * j + r16);
+        pair_ok[j] = v0 < prm.P;
+        const int n = v0 / prm.S;
+        pair_off[j] = n * prm.M * prm.S + (v0 - n * prm.S);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * i + 4 * g + r;
+            const int row_off = m * prm.S;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int v0 = n0 + 64 * wave + 2 * (16 * j + r16);
                 const float M0 = acc[0][i][j][r], M1 = acc[1][i][j][r], M2 = acc[2][i][j][r], M3 = acc[3][i][j][r];
                 f32x2 y = {(M0 + M1) + M2, (M1 - M2) - M3};
-                if (v0 < prm.P && m < prm.M) {
+                if (pair_ok[j] && m < prm.M) {
                     s1 += y[0] + y[1];
                     s2 += y[0] * y[0] + y[1] * y[1];
-                    const int n = v0 / prm.S, sl = v0 - n * prm.S;
-                    const size_t off = ((size_t)n * prm.M + m) * prm.S + sl;
+                    const int off = pair_off[j] + row_off;
                     if (prm.add != nullptr) y += *reinterpret_cast<const f32x2*>(prm.add + off);
                     if (prm.bias != nullptr) y += prm.bias[m];
                     if (prm.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); }
