@@ -11,12 +11,15 @@
 // i.e. 4 multiplies per output pair instead of 6: 1.5x fewer MFMAs, still fp32 in / fp32 accumulate
 // (the only rounding added is the 3-term sums of U, ~1e-7 relative).
 //
-// Implicit GEMM per point i: rows = 64 output channels (4 blocks), columns = 128 voxel PAIRS per
+// Implicit GEMM per point i: rows = 64 or 48 output channels (4 / 3 blocks), columns = 128 voxel PAIRS per
 // workgroup (4 waves x 2 blocks of 16 pairs = 256 consecutive voxels; W is even, so a pair never
-// straddles a row), K = (16-channel block, kh).  Per chunk the four U panels [16][64] and ONE raw input
-// image [16][256 + 2 halo] are staged by LDS-DMA; the V transform happens on the B fragment in
-// registers (two ds_read_b64 + 4 VALU give the fragments of all four points), so the input is gathered
-// once per (block, kh) instead of once per tap.  Row ends (w-1 < 0, w+2 >= W) zero d0 / d3 per lane.
+// straddles a row), K = (16-channel block, row tap).  Per chunk the four U panels [16][rows] and ONE raw input
+// image [16][256 + 2 halo] are staged by LDS-DMA (16-byte pieces when W % 4 == 0); the V transform happens on
+// the B fragment in registers (an aligned ds_read_b64 + 2 single reads + 4 VALU give the fragments of all four
+// points), so the input is gathered once per (block, row tap) instead of once per tap.  Row ends (w-1 < 0,
+// w+2 >= W) zero d0 / d3 per lane.  Epilogue: output transform, then BatchNorm partial statistics / + add / + bias /
+// ReLU as the caller asks.  Problems with fewer tiles than one round of workgroups run in 2-4 K parts (slabs summed in
+// order by splitk_reduce).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
         const float* as = pool + cur * STAGE;
         const float* bs = as + A_FLOATS;
-        // fragments of k-step s+1 are fetched before the MFMA burst of step s (ZSV_WINO_PIPE)
+        // fragments of k-step s+1 are fetched before the MFMA burst of step s
         float a[2][4][TM];
         f32x2 lo[2][2], hi[2][2];
         auto fetch = [&](int s, int slot) {
