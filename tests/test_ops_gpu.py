@@ -702,3 +702,42 @@ def test_conv3d_winograd_split_k(cin, cout, k, use_bias, monkeypatch):
     if torch.equal(y > 0, y2 > 0):
         close(dx, dx2.double(), rtol=5e-6, what="winograd (K parts) vs direct kernel, dgrad")
     assert not torch.equal(dx, dx2), "the two paths should not be the same kernel"
+
+
+WGRAD_TRING_CASES = [
+    # name, N, Cin, (T,H,W), Cout
+    ("t1_like", 2, 144, (8, 32, 32), 64),                    # one 144-row tile, one column tile
+    ("cin230_cout128", 4, 230, (4, 32, 32), 128),            # two 128-row tiles (ragged), two column tiles, T = 4
+    ("ragged_both", 2, 130, (16, 16, 64), 56),               # channel padding on both sides
+    ("many_clips", 12, 144, (4, 16, 28), 64),                # HW = 448 = 28 segments; slices start mid-segment
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TRING_CASES, ids=[c[0] for c in WGRAD_TRING_CASES])
+def test_conv3d_wgrad_temporal_ring_path(case, monkeypatch):
+    """Weight gradient of the temporal 3x1x1 stride-1 convolutions through the dY-frame-ring kernel
+    (conv_wgrad_tring.hip) against torch CPU fp64 and the plain LDS-DMA kernel; bitwise reproducible."""
+    name, n, cin, (t, h, w), cout = case
+    g = torch.Generator().manual_seed(len(name) * 17 + cin)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    wshape = (cout, cin, 3, 1, 1)
+    ref = torch.nn.grad.conv3d_weight(x.double(), wshape, dy.double(), padding=(1, 0, 0))
+
+    def run():
+        wg = torch.zeros(wshape, device=DEV).requires_grad_()
+        ops.conv3d(x.to(DEV), wg, None, 1, (1, 0, 0)).backward(dy.to(DEV))
+        return wg.grad
+
+    a = run()
+    close(a, ref, what=f"{name} wgrad (frame ring)")
+    assert torch.equal(a, run()), "bitwise reproducible"
+    monkeypatch.setenv("ZSV_NO_WGRAD_TRING", "1")
+    b = run()
+    close(b, ref, what=f"{name} wgrad (plain)")
+    # (both kernels add the voxels of a slice in the same order, so with equal slice counts they can agree bit for bit)
+    monkeypatch.delenv("ZSV_NO_WGRAD_TRING")
+    monkeypatch.setenv("ZSV_WGRAD_TRING_SLICES", "7")
+    c = run()
+    close(c, ref, what=f"{name} wgrad (frame ring, 7 slices)")
+    assert not torch.equal(a, c), "the slice-count knob of the ring kernel had no effect: is the kernel in use?"

@@ -204,6 +204,12 @@ int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* wor
 // per-voxel tap-validity words of one clip (S words; bit tap <=> the tap's input voxel is inside): used by both
 // LDS-DMA weight-gradient kernels
 int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream);
+// weight gradient of the temporal 3x1x1 stride-1 convolutions with a ring of dY frames in LDS (conv_wgrad_tring.hip): slabs,
+// ordered reduction; writes dw
+bool wgrad_tring_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
+size_t wgrad_tring_workspace_bytes(const zsv_conv_desc* d);
+int wgrad_tring(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                hipStream_t stream);
 // Winograd-form weight gradient of the 1x3x3 / 3x3x3 stride-1 "same" convolutions (conv_wgrad_wino.hip): slabs, mask
 // table, ordered reduction and output transform; writes dw
 bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* dy);

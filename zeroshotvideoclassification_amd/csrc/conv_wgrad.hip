@@ -463,6 +463,10 @@ extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
         const size_t b = wgrad_wino_workspace_bytes(d);
         if (b > need) need = b;
     }
+    if (wgrad_tring_applicable(d, nullptr, nullptr)) {
+        const size_t b = wgrad_tring_workspace_bytes(d);
+        if (b > need) need = b;
+    }
     return need;
 }
 
@@ -477,6 +481,7 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
     if (wgrad_wino_applicable(d, x, dy)) return wgrad_wino(d, x, dy, dw, workspace, workspace_bytes, stream);
+    if (wgrad_tring_applicable(d, x, dy)) return wgrad_tring(d, x, dy, dw, workspace, workspace_bytes, stream);
     if (wgrad_dma_applicable(d, x, dy)) {
         int slices = 0, cpad = 0;
         st = wgrad_dma(d, x, dy, workspace, workspace_bytes, &slices, &cpad, stream);
