@@ -13,10 +13,11 @@
 //
 // Implicit GEMM per point i: rows = 64 or 48 output channels (4 / 3 blocks), columns = 128 voxel PAIRS per
 // workgroup (4 waves x 2 blocks of 16 pairs = 256 consecutive voxels; W is even, so a pair never
-// straddles a row), K = (16-channel block, row tap).  Per chunk the four U panels [16][rows] and ONE raw input
+// straddles a row), K = (16-channel block, row tap).  Per chunk the four U panels [rows][16 k] and ONE raw input
 // image [16][256 + 2 halo] are staged by LDS-DMA (16-byte pieces when W % 4 == 0); the V transform happens on
 // the B fragment in registers (an aligned ds_read_b64 + 2 single reads + 4 VALU give the fragments of all four
-// points), so the input is gathered once per (block, row tap) instead of once per tap.  Row ends (w-1 < 0,
+// points), so the input is gathered once per (block, row tap) instead of once per tap.  MFMA k order k = 4*(lane>>4) + step:
+// a lane's U values for the 4 steps of a chunk are one ds_read_b128 per (point, row block).  Row ends (w-1 < 0,
 // w+2 >= W) zero d0 / d3 per lane.  Epilogue: output transform, then BatchNorm partial statistics / + add / + bias /
 // ReLU as the caller asks.  Problems with fewer tiles than one round of workgroups run in 2-4 K parts (slabs summed in
 // order by splitk_reduce).
@@ -49,14 +50,14 @@ struct WinoParams {
     float* stat_sq;         //   [M][tiles_n] each (BatchNorm statistics of a training forward)
 };
 
-// Up[((cb*R + r)*4 + pt)*16 + c%16][Mp] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
+// Up[(cb*R + r)*4 + pt][Mp][c%16] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
                                                         int C, int nblk, int R, long sm, long sc, int flip, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int m = (int)(i % Mp);
-        long r = i / Mp;
-        const int c16 = (int)(r % 16);
-        r /= 16;
+        const int c16 = (int)(i % 16);
+        long r = i / 16;
+        const int m = (int)(r % Mp);
+        r /= Mp;
         const int pt = (int)(r % 4);
         r /= 4;
         const int kh = (int)(r % R);
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 16 * TM, BN = 256, BK = 16;
-    constexpr int LDA = BM % 32 == 16 ? BM : BM + 16;   // k-major rows, ds_read_b32 conflict-free (pitch = 16 mod 32)
-    static_assert(LDA % 32 == 16, "A pitch");
-    constexpr int LDB = 288;                // 258 (261) used; = 32 mod 64 so the two k rows of a ds_read_b64 pass split the banks
+    // MFMA k order k = 4*(lane>>4) + step: the U image is [point][row][16 k] (64-byte rows, 16-byte slot XOR-swizzled on the
+    // source side), so a lane reads its row's k values for the 4 steps of a chunk with ONE ds_read_b128 per (point, row block)
+    constexpr int LDB = 264;                // 258 (261) used; 4 * LDB = 32 mod 64: the k rows 4g+s of the two lane halves of a ds_read_b64 split the banks
     constexpr int C0 = X4 ? 4 : 1;          // image column of the tile's first voxel (16-byte aligned for the 16-byte DMAs); halo at C0-1, C0+256
-    constexpr int A_FLOATS = 4 * BK * LDA, B_FLOATS = BK * LDB;
+    constexpr int A_FLOATS = 4 * BM * BK, B_FLOATS = BK * LDB;
     constexpr int HALO_AT = A_FLOATS + B_FLOATS;      // 64 floats of scratch: where the halo DMA lands
     constexpr int STAGE = HALO_AT + 64;
     constexpr unsigned OOB = 0xFFFFFFFFu, OOB16 = 0xFFFFFFF0u;      // (+12 must not wrap)
@@ -129,16 +130,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
     unsigned halo_mask = 0;
     if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
 
-    // U panels: linear image of [4][16][LDA]; 16-byte slots
-    constexpr int ASLOTS = A_FLOATS / 4;
-    constexpr int APASS = (ASLOTS + 255) / 256;
+    // U panels: 4*TM pieces of 16 rows x 64 B; lane l of a piece fills row l/4, slot l%4 <- source slot (l%4) ^ swz(row)
+    constexpr int APASS = TM;                         // pieces per wave: piece q = wave + 4*j = (point q / TM, row block q % TM)
     const float* a_src[APASS];
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-        int slot = 64 * (wave + 4 * j) + lane;
-        slot = slot < ASLOTS ? slot : ASLOTS - 1;                        // (surplus lanes repeat the last slot)
-        const int row = slot / (LDA / 4), c4 = slot % (LDA / 4);         // row = pt*16 + k
-        a_src[j] = Up + (size_t)row * prm.Mp + m0 + (c4 < BM / 4 ? 4 * c4 : 0);
+        const int q = wave + 4 * j, pt = q / TM, ib = q % TM, row = lane >> 2;
+        const int sw = ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 4;
+        a_src[j] = Up + ((size_t)pt * prm.Mp + m0 + 16 * ib + row) * 16 + sw;
     }
     const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
 
@@ -183,8 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         }
 #pragma unroll
         for (int j = 0; j < APASS; ++j)
-            if (64 * (wave + 4 * j) < ASLOTS)              // wave-uniform
-                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
         if (++ld_kh == 3) {
             ld_kh = 0;
             if (++ld_kt == prm.kT) { ld_kt = 0; ++ld_cb; }
@@ -227,15 +225,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
         if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
         const float* as = pool + cur * STAGE;
         const float* bs = as + A_FLOATS;
-        // fragments of k-step s+1 are fetched before the MFMA burst of step s
-        float a[2][4][TM];
+        // U fragments of the whole chunk up front (one ds_read_b128 each); image fragments of k-step s+1 are fetched before the
+        // MFMA burst of step s
+        f32x4 a4[4][TM];
+        const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
         f32x2 lo[2][2], hi[2][2];
         auto fetch = [&](int s, int slot) {
-            const int krow = 4 * s + g;
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[slot][p][i] = as[(p * 16 + krow) * LDA + 16 * i + r16];
+            const int krow = 4 * g + s;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float* src = bs + krow * LDB + (C0 - 1) + 64 * wave + 2 * (16 * j + r16);       // image column of d0
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][p][i], v[p][j], acc[p][i][j], 0, 0, 0);
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p][j], acc[p][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -397,8 +397,7 @@ bool wino_fwd_fusable(const zsv_conv_desc* d) { return wino_ksplit(d, d->Cout) =
 
 template <int TM, int NCHUNKS, bool X4>
 static int wino_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
-    constexpr int LDA = (16 * TM) % 32 == 16 ? 16 * TM : 16 * TM + 16;          // as in the kernel
-    constexpr int LDS_BYTES = 2 * (4 * 16 * LDA + 16 * 288 + 64) * 4;
+    constexpr int LDS_BYTES = 2 * (4 * 16 * TM * 16 + 16 * 264 + 64) * 4;        // as in the kernel
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino_kernel<TM, NCHUNKS, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
