@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: clips/sec of one full R(2+1)D-18 training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts one child process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -44,6 +44,65 @@ FRAMES, SIZE = 16, 112
 FP32_MFMA_PEAK_TFLOPS = 157.3
 # S1 of SURVEY section 2a: Conv3d(64, 144, (1,3,3), stride 1, pad (0,1,1)) on 16x56x56
 S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56)
+# the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step
+DOMINANT = {
+    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino_kernel<3, 12, true>",
+                        what="Conv3d(64,144,(1,3,3)) forward @16x56x56 (resnet.py:40-45, layer1 spatial half of Conv2Plus1D)"),
+    # network.py:105 conv2 = Conv3d(64,128,3x3x3, pad 1) after pool1 (1,2,2): 22.2 GFLOP/clip, 29 % of C3D's forward FLOPs
+    "c3d": dict(geometry=dict(Cin=64, Cout=128, kT=3, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56), launches=1,
+                symbol="zsv::conv_wino_kernel<4, 0, true>",
+                what="Conv3d(64,128,3x3x3) forward @16x56x56 (network.py:105 conv2)"),
+}
+BASELINE_CONFIG = {"r2plus1d_18": "BASELINE.json configs[1]; configs[2] when n_gpus > 1", "c3d": "BASELINE.json configs[3]"}
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_commands(n_gpus: int, argv, port: int, script: str = os.path.abspath(__file__)):
+    """One ``(command, environment overrides)`` pair per rank: what ``torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1`` would hand each worker.  Pure function (tested on CPU)."""
+    jobs = []
+    for rank in range(n_gpus):
+        env = {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n_gpus), "LOCAL_WORLD_SIZE": str(n_gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+               "ZSV_BENCH_CHILD": "1"}
+        jobs.append(([sys.executable, script] + list(argv), env))
+    return jobs
+
+
+def launch_children(n_gpus: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher: start one fresh process per GPU (the reference's
+    ``opt.bs *= n_gpu`` + ``nn.DataParallel``, main.py:61-63,126, becomes one rank per device).  The parent
+    never touches the GPU (``device_count()`` does not initialise it on this image) and never execs; rank
+    0's stdout -- the one JSON line -- is this process's stdout.  Non-zero exit if any rank fails."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    procs = []
+    for cmd, extra in child_commands(n_gpus, argv, free_port()):
+        env = dict(os.environ)
+        env.update(extra)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if extra["RANK"] == "0" else subprocess.DEVNULL))
+    failed = 0
+    while procs:
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0 and not failed:
+                failed = rc
+                for q in procs:                       # a dead rank leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.2)
+    return failed
 
 
 def parse():
@@ -140,7 +199,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(launch_children(args.gpus, sys.argv[1:]))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
 
@@ -180,7 +239,8 @@ def main():
         train.train_step(model, optimizer, criterion, x, z, sync)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
-    timer = ops.KernelTimer("conv_fwd", dict(S1_GEOMETRY, N=args.batch)) if args.network.startswith("r2plus1d") else None
+    dom = DOMINANT.get(args.network)
+    timer = ops.KernelTimer("conv_fwd", dict(dom["geometry"], N=args.batch)) if dom else None
     ops.KERNEL_TIMER = timer
     barrier()
     t0 = time.perf_counter()
@@ -223,19 +283,30 @@ def main():
     if rank == 0:
         total_clips = world * args.batch * args.steps
         value = total_clips / elapsed
-        label = {"r2plus1d_18": "R(2+1)D-18"}.get(args.network, args.network)
+        label = {"r2plus1d_18": "R(2+1)D-18", "c3d": "C3D", "r3d_18": "R3D-18"}.get(args.network, args.network)
+        which = BASELINE_CONFIG.get(args.network, "not a BASELINE.json config")
+        if args.network == "r2plus1d_18":
+            which = "BASELINE.json configs[1]" if world == 1 else f"BASELINE.json configs[2] at {world} GPUs"
+        if args.batch != CLIPS_PER_GPU:
+            which += f", but {args.batch} clips/GPU instead of {CLIPS_PER_GPU}"
         out = {
             "metric": f"clips/sec (fwd+bwd+step) {label} 16x112x112 bs={args.batch}/GPU",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.network} training step (zero_grad+fwd+MSE+bwd+Adam), {args.batch} clips/GPU "
-                                   f"3x{FRAMES}x{SIZE}x{SIZE}, random-init, fp32 (BASELINE.json configs[1])",
+                                   f"3x{FRAMES}x{SIZE}x{SIZE}, random-init, fp32 ({which})",
                        "clips_per_gpu": args.batch, "global_batch": world * args.batch,
                        "optimizer": "Adam lr=1e-3 (" + ("fused multi-tensor HIP kernel" if args.optimizer == "fused" else "torch.optim.Adam") + ")",
                        "parallelism": f"dp{world}" + (" RCCL bucketed all-reduce overlapped with backward" if world > 1 else ""),
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "launcher": "self (one child process per GPU)" if os.environ.get("ZSV_BENCH_CHILD") else
+                                   ("torch.distributed.run" if world > 1 else "single process"),
                        "final_loss": float(loss.item()) if loss is not None else None},
         }
+        if sync is not None:
+            out["config"]["allreduce_bytes_per_step"] = int(sync.bytes_reduced_last_step)
+            out["config"]["allreduce_buckets"] = len(sync.bucket_sizes)
         # whole-step fractions of the two rooflines SURVEY section 8d defines
         per_gpu = value / world
         if args.network.startswith("r2plus1d"):
@@ -245,22 +316,26 @@ def main():
             ms = timer.durations_ms()
             mean_ms = sum(ms) / len(ms)
             n = args.batch
-            flops = 2.0 * n * 144 * 64 * 9 * 16 * 56 * 56          # 8.324 GFLOP/clip: the direct-convolution count
-            alg_bytes = 4.0 * (n * 64 * 16 * 56 * 56 + n * 144 * 16 * 56 * 56 + 144 * 64 * 9)
+            gm = dom["geometry"]
+            taps = gm["kT"] * gm["kH"] * gm["kW"]
+            voxels = gm["Ti"] * gm["Hi"] * gm["Wi"]                 # stride 1, "same" padding: output voxels = input voxels
+            flops = 2.0 * n * gm["Cout"] * gm["Cin"] * taps * voxels   # direct-convolution count (S1: 8.324 GFLOP/clip)
+            alg_bytes = 4.0 * (n * gm["Cin"] * voxels + n * gm["Cout"] * voxels + gm["Cout"] * gm["Cin"] * taps)
             achieved = flops / (mean_ms * 1e-3) / 1e12
             # the kernel computes the kw taps in Winograd F(2,3) form: 4 multiplies per output pair instead of 6,
-            # so the matrix pipe executes 2/3 of the algorithmic FLOPs (counter-checked: profiles/r01_s1_mfma_busy.json)
+            # so the matrix pipe executes 2/3 of the algorithmic FLOPs (counter-checked: profiles/*_mfma_busy.json)
             executed = flops * 2.0 / 3.0 / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "zsv::conv_wino_kernel<3, 12, true> = Conv3d(64,144,(1,3,3)) forward @16x56x56 "
-                                         "(fp32 Winograd F(2,3) along W + its weight-transform launch), 4 launches/step",
+            out["roofline"] = {"kernel": f"{dom['symbol']} = {dom['what']} "
+                                         f"(fp32 Winograd F(2,3) along W + its weight-transform launch), {dom['launches']} launch(es)/step",
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "achieved_is": "algorithmic (direct-convolution) FLOPs / time, as SURVEY 8d counts them",
+                               "achieved_is": "ALGORITHMIC (direct-convolution) FLOPs / time, as SURVEY 8d counts them; this is not "
+                                              "pipe utilisation: the Winograd form executes 2/3 of them -> mfma_executed_frac",
                                "mfma_executed_tflops": round(executed, 2),
                                "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                                "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
                                "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
-                               "traffic": pmc_traffic(n)}
+                               "traffic": pmc_traffic(n) if args.network == "r2plus1d_18" else None}
         if phases is not None:
             out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:

@@ -172,6 +172,18 @@ int zsv_linear_wgrad(const float* x, const float* dy, float* dw, int32_t rows,
                      int32_t in_features, int32_t out_features, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- cosine nearest classes (evaluate / train accuracy) -------------------------------------- */
+/* cdist(embed, class_embed, 'cosine').argsort(1)[:, :k] of compute_accuracy (main.py:316-325; k = 5 and
+ * k = 1) and of the per-step train accuracy (main.py:182-185).  embed (rows, dim) and class_embed
+ * (n_classes, dim) fp32, not necessarily normalised.  Distances 1 - <u,v>/(|u||v|) are formed in double
+ * precision on the matrix core (v_mfma_f64_16x16x4_f64), like scipy's double cdist; out_index (rows, k)
+ * int32 = the k nearest classes, ties by lower index (stable argsort); out_dist (rows, k) double may be
+ * NULL.  workspace = the (rows, n_classes rounded up to 16) double distance matrix. */
+size_t zsv_cosine_topk_workspace_bytes(int32_t rows, int32_t n_classes);
+int zsv_cosine_topk(const float* embed, const float* class_embed, int32_t rows, int32_t dim, int32_t n_classes,
+                    int32_t k, int32_t* out_index, double* out_dist, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
 /* ---- optimiser ------------------------------------------------------------------ */
 /* One torch.optim.Adam step (main.py:131; betas (0.9, 0.999), eps 1e-8, no weight decay,
  * no amsgrad) over a flat fp32 buffer: p, g, exp_avg, exp_avg_sq of n elements.

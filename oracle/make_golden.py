@@ -27,7 +27,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oracle import restatement as R                                   # noqa: E402
-from oracle.reference_import import import_reference                    # noqa: E402
+from oracle.reference_import import (import_reference, import_reference_transforms,    # noqa: E402
+                                     reference_main_functions)
+from oracle import transforms_oracle as TO                              # noqa: E402
 from zeroshotvideoclassification_amd import synthetic as S             # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -181,11 +183,116 @@ def run_case(case, ref_network):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# clip transforms: outputs of the reference's own ``get_transform`` chains
+TRANSFORM_SIZES = [(120, 160), (240, 320), (128, 171), (200, 130)]
+
+
+def transform_input(h: int, w: int, frames: int = 1) -> torch.Tensor:
+    """The uint8 ``(T, H, W, 3)`` clip of a transforms case (regenerated by the tests)."""
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    return torch.randint(0, 256, (frames, h, w, 3), dtype=torch.uint8, generator=g)
+
+
+def run_transforms():
+    """``get_transform(True)`` / ``get_transform(False)`` (transforms.py:41-56) of the reference on seeded
+    uint8 clips.  The training chain draws its crop / flip from Python's ``random``: the draws are
+    replayed through ``preprocess.ClipTransform.draw_params`` (same seed) and must reproduce the
+    reference's output through the restatement bit for bit -- that pins the draw order too."""
+    import random
+    from zeroshotvideoclassification_amd import preprocess
+    RT = import_reference_transforms()
+    out = {"sizes": np.array(TRANSFORM_SIZES)}
+    for k, (h, w) in enumerate(TRANSFORM_SIZES):
+        clip = transform_input(h, w)
+        hres, wres, _ = preprocess.resized_hw(h, w, 128)
+        val = RT.get_transform(True)(clip)
+        assert tuple(val.shape) == (3, 1, 112, 112)
+        ci, cj = TO.center_crop_params(hres, wres, 112, 112)
+        assert torch.equal(val, TO.clip_transform(clip, ci, cj, False)), "restatement differs (validation chain)"
+        out[f"val_{h}x{w}"] = val.numpy()
+        seed = 100 + k
+        random.seed(seed)
+        trn = RT.get_transform(False)(clip)
+        random.seed(seed)
+        (i, j, f), = preprocess.ClipTransform(False).draw_params(1, hres, wres)
+        assert torch.equal(trn, TO.clip_transform(clip, i, j, bool(f))), "restatement / draw order differs (training chain)"
+        out[f"train_{h}x{w}"] = trn.numpy()
+        out[f"train_params_{h}x{w}"] = np.array([seed, i, j, f])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluate() / compute_accuracy() (SURVEY a15): the reference's own functions on synthetic embeddings
+EVAL_SETS = [dict(name="ucf101", classes=101, n=1500), dict(name="hmdb51", classes=51, n=900),
+             dict(name="activitynet", classes=200, n=2000)]
+
+
+def run_accuracy():
+    """``evaluate`` (main.py:224-313) and ``compute_accuracy`` (main.py:316-325) compiled from the
+    reference's text (``reference_main_functions``) and run with stand-ins for their globals: the
+    "model" returns its input (the batches carry the predicted embeddings), the loader yields
+    ``(X, l, Z, _)`` batches with some broken samples (label -1), ``opt.split == -1`` selects the
+    10-split protocol, and the tensorboard writer records the scalars."""
+    import tempfile
+    from types import SimpleNamespace
+    from scipy.spatial.distance import cdist
+    from sklearn.metrics import accuracy_score
+    out = {}
+    for spec in EVAL_SETS:
+        table, labels, true, pred = S.synthetic_eval_set(spec["n"], spec["classes"], broken=7)
+        scalars = {}
+        writer = SimpleNamespace(add_scalar=lambda tag, v, epoch: scalars.__setitem__(tag, float(v)))
+        dataset = SimpleNamespace(name=spec["name"], class_embed=table.numpy())
+        dataset_len = spec["n"]
+
+        class Loader:
+            def __init__(self):
+                self.dataset = type("D", (), {"name": dataset.name, "class_embed": dataset.class_embed,
+                                              "__len__": lambda self_: dataset_len})()
+
+            def __iter__(self):
+                for a in range(0, spec["n"], 64):
+                    yield pred[a:a + 64], labels[a:a + 64], true[a:a + 64], None
+
+        with tempfile.TemporaryDirectory() as tmp:
+            opt = SimpleNamespace(dataset="synthetic", progressbar=False, device="cpu", savename=tmp, split=-1)
+            ns = reference_main_functions(
+                model=torch.nn.Identity(), opt=opt, np=np, torch=torch, cdist=cdist, accuracy_score=accuracy_score,
+                tqdm=lambda it, **_k: it, Fore=SimpleNamespace(RED="", GREEN=""), Style=SimpleNamespace(RESET_ALL=""))
+            acc, acc5 = ns["evaluate"](Loader(), writer, 0)
+        keep = labels != -1
+        mine = R.evaluate_protocol(pred[keep].numpy(), true[keep].numpy(), labels[keep].numpy(), table.numpy())
+        name = spec["name"]
+        got = {"accuracy": acc, "accuracy_top5": acc5, "split_accuracy": scalars[name + "/AccSplit_Mean"],
+               "split_accuracy_std": scalars[name + "/AccSplit_Std"],
+               "split_accuracy_top5": scalars[name + "/AccSplit_Mean_Top5"],
+               "split_accuracy_top5_std": scalars[name + "/AccSplit_Std_Top5"]}
+        assert scalars[name + "/Accuracy"] == acc and scalars[name + "/Accuracy_Top5"] == acc5
+        for k, v in got.items():
+            assert mine[k] == v, f"restatement of evaluate differs from the reference: {name} {k} {mine[k]} {v}"
+        direct = ns["compute_accuracy"](pred[keep].numpy(), table.numpy(), true[keep].numpy())
+        assert tuple(direct) == (acc, acc5)
+        out[name + "_spec"] = np.array([spec["classes"], spec["n"], 7])
+        out[name + "_expected"] = np.array([got[k] for k in sorted(got)])
+        out[name + "_keys"] = np.array(sorted(got))
+        out[name + "_n_kept"] = np.array(int(keep.sum()))
+        print(f"  {name}: " + ", ".join(f"{k}={v:.4f}" for k, v in got.items()), flush=True)
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     ref_network, _ = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
+    for name, fn in (("transforms", run_transforms), ("accuracy", run_accuracy)):
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        path = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(path, **fn(), meta_torch=np.array(torch.__version__))
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.1f}s", flush=True)
     for case in CASES:
         if only and case["name"] not in only:
             continue

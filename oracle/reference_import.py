@@ -72,3 +72,63 @@ def import_reference():
     resnet = importlib.import_module("resnet")
     network = importlib.import_module("network")
     return network, resnet
+
+
+def import_reference_transforms():
+    """The reference's ``auxiliary/transforms.py`` (build container only).
+
+    It imports ``imageio`` (used by ``batch2gif`` only, transforms.py:70-77) and
+    ``torchvision.transforms`` (only ``Compose``, transforms.py:56); neither carries arithmetic of
+    the clip chain, so an empty ``imageio`` module and a ``Compose`` that applies its list in order
+    stand in for them when the packages are absent.  Every function that touches pixel values
+    (``to_normalized_float_tensor``, ``resize``, ``crop``, ``center_crop``, ``RandomCrop``,
+    ``RandomHorizontalFlip``) is the reference's own code."""
+    if not reference_available():
+        raise FileNotFoundError(REFERENCE_ROOT)
+    sys.dont_write_bytecode = True
+    try:
+        importlib.import_module("imageio")
+    except Exception:
+        _stub("imageio")
+
+    class Compose:                                        # torchvision.transforms.Compose: apply in order
+        def __init__(self, transforms):
+            self.transforms = transforms
+
+        def __call__(self, x):
+            for t in self.transforms:
+                x = t(x)
+            return x
+
+    try:
+        importlib.import_module("torchvision.transforms")
+    except Exception:
+        tv = _stub("torchvision")
+        tv.transforms = _stub("torchvision.transforms", Compose=Compose)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    mod = sys.modules.get("auxiliary.transforms")
+    if mod is not None and not getattr(mod, "__file__", "").startswith(REFERENCE_ROOT):
+        del sys.modules["auxiliary.transforms"]
+    return importlib.import_module("auxiliary.transforms")
+
+
+def reference_main_functions(names=("evaluate", "compute_accuracy"), **globals_):
+    """Compile single functions of the reference's ``main.py`` WITHOUT running the module.
+
+    ``main.py`` cannot be imported (module-level argparse, ``torch.device('cuda')`` and the dataset
+    build, main.py:55-111), but ``evaluate`` (main.py:224-313) and ``compute_accuracy``
+    (main.py:316-325) are self-contained given their globals.  The file is parsed with ``ast``,
+    the named ``FunctionDef`` nodes are compiled from the reference's own text and executed in a
+    namespace holding ``globals_`` (the caller supplies ``model``, ``opt``, ``Fore`` ... stand-ins
+    plus the real ``np``, ``torch``, ``cdist``, ``accuracy_score``).  Nothing of the text is stored."""
+    import ast
+    path = os.path.join(REFERENCE_ROOT, "main.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    if sorted(n.name for n in picked) != sorted(names):
+        raise RuntimeError(f"main.py does not define {names}")
+    ns = dict(globals_)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns

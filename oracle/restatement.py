@@ -13,8 +13,8 @@ reference builds in ``resnet.py`` and ``network.py``:
   output handling
 
 Module attribute names / Sequential indices are chosen so ``state_dict()`` keys are
-identical to the reference's (checked by ``tests/test_oracle_pins_reference.py`` in the
-build container, and pinned for the GPU box by ``tests/golden``).  Arithmetic is
+identical to the reference's (checked by ``tests/test_oracle.py::test_restatement_is_pinned_to_the_imported_reference``
+in the build container, and pinned for the GPU box by ``tests/golden``).  Arithmetic is
 whatever ``torch.nn.functional`` does on CPU in the dtype of the parameters (fp32, or
 fp64 after ``.double()``).
 """
@@ -264,3 +264,27 @@ def compute_accuracy(pred: torch.Tensor, classes: torch.Tensor, true: torch.Tens
     top1 = float(np.mean(order[:, 0] == y) * 100)
     top5 = float(np.mean([t in p for t, p in zip(y, order[:, :5])]) * 100)
     return top1, top5
+
+
+def evaluate_protocol(pred, true, label, classes, splits: int = 10) -> Dict[str, float]:
+    """What ``evaluate`` (main.py:224-313) computes once the embeddings are collected: accuracy over all
+    classes (main.py:264-266) and, for ``opt.split == -1``, the ten seeded half-class splits
+    (main.py:281-304): ``np.random.seed(split)``, the first half of a permutation of the class indices,
+    samples whose label is in it, accuracy against THAT half of the class table; mean / std over the
+    splits of top-1 and top-5.  numpy arrays in, python floats out."""
+    import numpy as np
+    pred, true, classes = (np.asarray(a, dtype=np.float32) for a in (pred, true, classes))
+    label = np.asarray(label).astype(np.int64)
+    acc, acc5 = compute_accuracy(torch.from_numpy(pred), torch.from_numpy(classes), torch.from_numpy(true))
+    out = {"accuracy": acc, "accuracy_top5": acc5, "n": int(len(pred))}
+    a1, a5 = np.zeros(splits), np.zeros(splits)
+    for split in range(splits):
+        np.random.seed(split)
+        chosen = np.random.permutation(len(classes))[:len(classes) // 2]
+        sel = np.isin(label, chosen)
+        a1[split], a5[split] = compute_accuracy(torch.from_numpy(pred[sel]), torch.from_numpy(classes[chosen]),
+                                                torch.from_numpy(true[sel]))
+    if splits:
+        out.update(split_accuracy=float(a1.mean()), split_accuracy_std=float(a1.std()),
+                   split_accuracy_top5=float(a5.mean()), split_accuracy_top5_std=float(a5.std()))
+    return out

@@ -5,8 +5,11 @@ Restates ``auxiliary/transforms.py`` with the same torch calls the reference mak
 align_corners=False, scale_factor = size / short side), ``crop`` (:60-61), ``center_crop``
 (:80-85), ``hflip`` (:88-89) and ``get_transform``'s order (:41-56: normalise -> resize -> crop
 -> flip).  Crop / flip parameters are explicit so the GPU path can be driven with the same ones.
-The reference's file itself is not importable offline (it imports ``torchvision.transforms`` and
-``imageio``); parity for this row is therefore pinned by this restatement of its torch calls only.
+Pinned to the reference: ``oracle/make_golden.py::run_transforms`` imports the reference's file in the build
+container (``oracle/reference_import.import_reference_transforms``: ``imageio`` and
+``torchvision.transforms.Compose`` are absent offline and carry no pixel arithmetic, so an empty module and an
+apply-in-order ``Compose`` stand in), asserts that this restatement equals ``get_transform(True/False)`` bit for
+bit and stores the reference's outputs in ``tests/golden/transforms.npz``.
 """
 from __future__ import annotations
 

@@ -1,0 +1,173 @@
+"""evaluate() / compute_accuracy() / train accuracy against the reference's own functions.
+
+``tests/golden/accuracy.npz`` holds what the reference's ``evaluate`` (main.py:224-313, incl. the ten
+``np.random.seed(split)`` half-class splits) and ``compute_accuracy`` (main.py:316-325) returned in the
+build container on the seeded embeddings of ``synthetic.synthetic_eval_set`` for class tables of 101 /
+51 / 200 classes (``oracle/make_golden.py::run_accuracy``).  CPU: the oracle restatement reproduces
+them.  GPU: the product (``train.evaluate`` / ``compute_accuracy`` / ``train_accuracy`` /
+``nearest_classes`` -> ``zsv_cosine_topk``) must give exactly the same numbers.
+"""
+import os
+import socket
+import sys
+from ctypes import c_void_p
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import restatement as R
+from zeroshotvideoclassification_amd import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SETS = ["ucf101", "hmdb51", "activitynet"]
+
+
+def _case(name):
+    g = load_golden("accuracy")
+    n_classes, n, broken = (int(v) for v in g[name + "_spec"])
+    table, labels, true, pred = synthetic.synthetic_eval_set(n, n_classes, broken=broken)
+    expected = dict(zip((str(k) for k in g[name + "_keys"]), (float(v) for v in g[name + "_expected"])))
+    return table, labels, true, pred, expected, int(g[name + "_n_kept"])
+
+
+def _batches(pred, labels, true, size=64):
+    return [(pred[a:a + size], labels[a:a + size], true[a:a + size], None) for a in range(0, len(pred), size)]
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_oracle_protocol_reproduces_the_reference(name):
+    table, labels, true, pred, expected, n_kept = _case(name)
+    keep = labels != -1
+    assert int(keep.sum()) == n_kept
+    got = R.evaluate_protocol(pred[keep].numpy(), true[keep].numpy(), labels[keep].numpy(), table.numpy())
+    for k, v in expected.items():
+        assert got[k] == v, (k, got[k], v)
+    assert 40.0 < expected["accuracy"] < 95.0 and expected["accuracy_top5"] > expected["accuracy"]   # a real test, not 0 / 100 %
+
+
+def test_product_refuses_cpu_tensors():
+    from zeroshotvideoclassification_amd import train
+    table, labels, true, pred = synthetic.synthetic_eval_set(8, 11)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        train.compute_accuracy(pred, table, true)
+
+
+# ----------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SETS)
+def test_evaluate_matches_the_reference_exactly(name):
+    from zeroshotvideoclassification_amd import train
+    table, labels, true, pred, expected, n_kept = _case(name)
+    dev = torch.device("cuda:0")
+    res = train.evaluate(torch.nn.Identity(), _batches(pred, labels, true), table, device=dev)
+    assert res["n"] == n_kept
+    for k, v in expected.items():
+        assert res[k] == v, (k, res[k], v)                                  # top-1, top-5, split means / stds: exact
+    keep = labels != -1
+    top1, top5 = train.compute_accuracy(pred[keep].to(dev), table.to(dev), true[keep].to(dev))
+    assert (top1, top5) == (expected["accuracy"], expected["accuracy_top5"])
+    # per-step train accuracy (main.py:182-185): argmin of the cosine distance == label
+    from scipy.spatial.distance import cdist
+    want = float(np.mean(cdist(pred[keep].numpy(), table.numpy(), "cosine").argmin(1) == labels[keep].numpy()) * 100)
+    got = train.train_accuracy(pred[keep].to(dev), table.to(dev), labels[keep].to(dev))
+    assert got.is_cuda and abs(got.item() - want) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,n_classes,dim,k", [(1, 5, 300, 5), (37, 51, 300, 5), (200, 101, 300, 1), (129, 200, 300, 5),
+                                                  (33, 17, 7, 3), (16, 16, 4, 16), (5, 1000, 301, 8)])
+def test_cosine_topk_c_abi_against_scipy(rows, n_classes, dim, k):
+    """The raw C entry point: indices equal scipy's stable argsort, distances within 1e-13, ragged sizes
+    (rows / classes not multiples of 16, dim not a multiple of 4), unnormalised inputs, duplicate classes."""
+    from scipy.spatial.distance import cdist
+    from zeroshotvideoclassification_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows * 1000 + n_classes)
+    e = torch.randn(rows, dim, generator=g) * 3.0
+    c = torch.randn(n_classes, dim, generator=g)
+    if n_classes > 8:
+        c[7] = c[2]                                                             # an exact tie: lower index first
+    dev = torch.device("cuda:0")
+    ed, cd = e.to(dev), c.to(dev)
+    idx = torch.full((rows, k), -7, dtype=torch.int32, device=dev)
+    dst = torch.zeros((rows, k), dtype=torch.float64, device=dev)
+    nbytes = lib.zsv_cosine_topk_workspace_bytes(rows, n_classes)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.zsv_cosine_topk(ed.data_ptr(), cd.data_ptr(), rows, dim, n_classes, k, idx.data_ptr(), dst.data_ptr(),
+                               ws.data_ptr(), nbytes, stream) == 0
+    torch.cuda.synchronize()
+    full = cdist(e.numpy(), c.numpy(), "cosine")
+    order = np.argsort(full, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx.cpu().numpy(), order)
+    assert np.abs(dst.cpu().numpy() - np.take_along_axis(full, order, 1)).max() < 1e-13
+    # error codes, no launch
+    assert lib.zsv_cosine_topk(ed.data_ptr(), cd.data_ptr(), rows, dim, n_classes, n_classes + 1, idx.data_ptr(), None,
+                               ws.data_ptr(), nbytes, stream) == 1               # ZSV_E_BAD_SHAPE
+    assert lib.zsv_cosine_topk(ed.data_ptr(), cd.data_ptr(), rows, dim, n_classes, k, idx.data_ptr(), None,
+                               ws.data_ptr(), nbytes - 8, stream) == 3           # ZSV_E_WORKSPACE
+    assert lib.zsv_cosine_topk(None, cd.data_ptr(), rows, dim, n_classes, k, idx.data_ptr(), None,
+                               ws.data_ptr(), nbytes, stream) == 2               # ZSV_E_NULL
+
+
+@pytest.mark.gpu
+def test_evaluate_edge_cases():
+    from zeroshotvideoclassification_amd import train
+    dev = torch.device("cuda:0")
+    table, labels, true, pred = synthetic.synthetic_eval_set(10, 4, seed=5)     # fewer than 5 classes: top-5 = all
+    res = train.evaluate(torch.nn.Identity(), _batches(pred, labels, true, 3), table, device=dev)
+    assert res["n"] == 10 and res["accuracy_top5"] == 100.0
+    want = R.evaluate_protocol(pred.numpy(), true.numpy(), labels.numpy(), table.numpy())
+    assert res["accuracy"] == want["accuracy"]
+    labels[:] = -1                                                              # every sample broken: nothing to score
+    res = train.evaluate(torch.nn.Identity(), _batches(pred, labels, true, 3), table, device=dev, splits=0)
+    assert res["n"] == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _sharded_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import json
+    import torch.distributed as dist
+    from zeroshotvideoclassification_amd import train
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        table, labels, true, pred, expected, n_kept = _case(name)
+        res = train.evaluate(torch.nn.Identity(), _batches(pred, labels, true, 50), table, device=dev)
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump(res, f)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_evaluate_two_ranks_equals_single_process(tmp_path):
+    """Config E's eval loop sharded over ranks (batch i -> rank i % world, all-gather of the rows): two
+    processes on cuda:0 with gloo transport give the single-process numbers, which are the reference's."""
+    import json
+    import torch.multiprocessing as mp
+    name = "activitynet"
+    mp.spawn(_sharded_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    *_, expected, n_kept = _case(name)
+    for rank in range(2):
+        with open(tmp_path / f"rank{rank}.json") as f:
+            res = json.load(f)
+        assert res["n"] == n_kept
+        for k, v in expected.items():
+            assert res[k] == v, (rank, k, res[k], v)

@@ -178,3 +178,29 @@ def test_bench_refuses_to_run_without_the_gpu():
     assert r.returncode != 0
     assert "MI355X" in (r.stderr + r.stdout)
     assert "clips/s" not in r.stdout
+
+
+def test_bench_self_launch_builds_one_child_per_gpu():
+    """`python bench.py --gpus N` without a launcher (the driver's SCALE run): one child per GPU with the
+    environment torch.distributed.run would give it, rendezvous on 127.0.0.1, the user's flags passed through;
+    fewer visible devices than N is a loud non-zero exit; the N = 1 path never spawns."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    jobs = bench.child_commands(4, argv, 29555)
+    assert len(jobs) == 4
+    for rank, (cmd, env) in enumerate(jobs):
+        assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py") and cmd[2:] == argv
+        assert env["RANK"] == env["LOCAL_RANK"] == str(rank) and env["WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29555"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("enough GPUs are present: the launch itself is exercised by bench.py --gpus 2")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "HIP device(s) are visible" in r.stderr and "clips/s" not in r.stdout
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src                # children are started, never exec'ed into

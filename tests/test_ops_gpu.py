@@ -179,6 +179,31 @@ def test_batchnorm_large_mean_is_stable():
     close(out, ref, rtol=2e-4, what="bn shifted")
 
 
+def test_batchnorm_mean_a_thousand_standard_deviations_away():
+    """|mean| / std ~ 1e3 per channel (and a different offset per channel): E[x^2] - mean^2 in fp32 would lose
+    the variance entirely; the shifted sums of bn_stats_kernel keep it.  Compared with the fp64 BatchNorm of the
+    SAME fp32-rounded inputs, forward, running statistics and input gradient."""
+    g = torch.Generator().manual_seed(11)
+    c = 7
+    offset = (torch.arange(c, dtype=torch.float32) - 3.0).view(1, c, 1, 1, 1) * 400.0 + 1000.0
+    x = torch.randn(6, c, 4, 12, 12, generator=g) + offset
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    dy = torch.randn(x.shape, generator=g)
+    xr = x.double().requires_grad_()
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    ref = F.batch_norm(xr, rm, rv, gamma.double(), beta.double(), training=True, momentum=0.1, eps=1e-5)
+    ref.backward(dy.double())
+    xg = x.to(DEV).requires_grad_()
+    rmg, rvg = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    out = ops.batch_norm_act(xg, gamma.to(DEV), beta.to(DEV), rmg, rvg, None, True, 0.1, 1e-5, False)
+    # x - mean is exact to ~1e-4 absolute at |x| ~ 2e3 in fp32: that bounds the achievable accuracy of xhat
+    close(out, ref, rtol=1e-3, what="bn far-from-zero mean")
+    close(rvg, rv, rtol=1e-4, what="running_var far-from-zero mean")
+    close(rmg, rm, rtol=1e-6, what="running_mean far-from-zero mean")
+    out.backward(dy.to(DEV))
+    close(xg.grad, xr.grad, rtol=2e-3, what="bn dx far-from-zero mean")
+
+
 def test_relu_add_relu_meanpool():
     g = torch.Generator().manual_seed(2)
     for numel_shape in [(3, 5, 2, 7, 7), (1, 1, 1, 1, 3), (2, 4, 4, 8, 8)]:

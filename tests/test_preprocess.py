@@ -1,11 +1,66 @@
-"""GPU clip pre-processing against the CPU restatement of transforms.py."""
+"""GPU clip pre-processing against outputs of the reference's own ``get_transform`` chains
+(``tests/golden/transforms.npz``, written by ``oracle/make_golden.py::run_transforms`` from the imported
+``auxiliary/transforms.py``) and against the CPU restatement that is pinned to them."""
 import random
 
+import numpy as np
 import pytest
 import torch
 
+from helpers import load_golden
 from oracle import transforms_oracle as TO
+from oracle.reference_import import reference_available
 from zeroshotvideoclassification_amd import preprocess
+
+
+def _golden_cases():
+    g = load_golden("transforms")
+    for h, w in g["sizes"]:
+        h, w = int(h), int(w)
+        clip = torch.randint(0, 256, (1, h, w, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(h * 1000 + w))
+        seed, i, j, f = (int(v) for v in g[f"train_params_{h}x{w}"])
+        yield h, w, clip, torch.from_numpy(g[f"val_{h}x{w}"]), torch.from_numpy(g[f"train_{h}x{w}"]), (seed, i, j, f)
+
+
+def test_restatement_and_draw_order_reproduce_the_reference_fixtures():
+    """CPU: the restatement equals the reference's validation and training chains bit for bit, and
+    ``ClipTransform.draw_params`` consumes Python's ``random`` in the reference's order
+    (RandomCrop.get_params: i then j, transforms.py:137-147; then RandomHorizontalFlip, :192-195)."""
+    n = 0
+    for h, w, clip, val, trn, (seed, i, j, f) in _golden_cases():
+        hres, wres, _ = preprocess.resized_hw(h, w, 128)
+        ci, cj = TO.center_crop_params(hres, wres, 112, 112)
+        assert torch.equal(TO.clip_transform(clip, ci, cj, False), val)
+        random.seed(seed)
+        assert preprocess.ClipTransform(False).draw_params(1, hres, wres) == [(i, j, f)]
+        assert torch.equal(TO.clip_transform(clip, i, j, bool(f)), trn)
+        assert preprocess.ClipTransform(True).draw_params(1, hres, wres) == [(ci, cj, 0)]
+        n += 1
+    assert n == 4
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference exists only in the build container")
+def test_fixtures_are_outputs_of_the_imported_reference():
+    from oracle.reference_import import import_reference_transforms
+    RT = import_reference_transforms()
+    for h, w, clip, val, trn, (seed, i, j, f) in _golden_cases():
+        assert torch.equal(RT.get_transform(True)(clip), val)
+        random.seed(seed)
+        assert torch.equal(RT.get_transform(False)(clip), trn)
+
+
+@pytest.mark.gpu
+def test_clip_transform_matches_the_reference_fixtures():
+    """The HIP kernel against the reference's outputs: validation chain (centre crop) and training chain
+    (the recorded random crop / flip), <= 2e-6 absolute on values in [-0.5, 0]."""
+    for h, w, clip, val, trn, (seed, i, j, f) in _golden_cases():
+        frames = clip.unsqueeze(0).cuda()
+        out = preprocess.get_transform(True)(frames).cpu()
+        assert out.shape == (1, 3, 1, 112, 112)
+        assert (out[0] - val).abs().max().item() < 2e-6, (h, w)
+        random.seed(seed)
+        out = preprocess.get_transform(False)(frames).cpu()                     # draws its own parameters
+        assert (out[0] - trn).abs().max().item() < 2e-6, (h, w)
 
 
 def test_resized_geometry_matches_interpolate():

@@ -72,6 +72,8 @@ SIGNATURES = {
     "zsv_clip_to_bf16": (c_int, [_P] + [c_int32] * 9 + [_P, _P]),
     "zsv_meanpool_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_clip_transform": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P, _P, _P]),
+    "zsv_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "zsv_cosine_topk": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "zsv_adam_multi": (c_int, [_P, c_int32, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
     "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
 }
@@ -105,3 +107,20 @@ def check(status: int, what: str) -> None:
     if status != 0:
         msg = load().zsv_status_string(int(status)).decode()
         raise RuntimeError(f"{what} failed: {msg} (zsv status {status})")
+
+
+# ---- writes the autograd version counters cannot see ---------------------------------------------
+# Kernels write through raw ``data_ptr()``s (BatchNorm running statistics, FusedAdam's parameter update),
+# and ``.data`` writes (``dist.broadcast(t.data)``, ``p.data = ...``) skip ``tensor._version`` as well.
+# Anything that caches values derived from parameters / buffers (``inference.engine_for``) keys on this
+# counter too; every such writer calls ``note_raw_write()``.
+_raw_write_generation = 0
+
+
+def note_raw_write() -> None:
+    global _raw_write_generation
+    _raw_write_generation += 1
+
+
+def raw_write_generation() -> int:
+    return _raw_write_generation

@@ -75,18 +75,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     const bool vec = (S % 4) == 0;
     int b, e;
     slice_range(N * S, slices, sl, vec, b, e);
+    // Shifted sums: a sample of the channel is the pivot K, so sum (x-K)^2 - (sum (x-K))^2 / n does not cancel
+    // when |mean| >> std (biased convolutions, post-ReLU features); x - K is exact or 1-ulp in fp32.
+    const float K = x[(size_t)c * S];
     float s1 = 0.f, s2 = 0.f;
     if (vec) {
         for (int i = b + 4 * (int)threadIdx.x; i < e; i += 4 * 256) {
             const int n = i / S, s = i - n * S;
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * S + s);
+            float4 v = *reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * S + s);
+            v.x -= K; v.y -= K; v.z -= K; v.w -= K;
             s1 += (v.x + v.y) + (v.z + v.w);
             s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
         for (int i = b + (int)threadIdx.x; i < e; i += 256) {
             const int n = i / S, s = i - n * S;
-            const float v = x[((size_t)n * C + c) * S + s];
+            const float v = x[((size_t)n * C + c) * S + s] - K;
             s1 += v;
             s2 += v * v;
         }
@@ -114,7 +118,10 @@ __global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __
     if (threadIdx.x == 0) { part[c] = t1; part[C + c] = t2; }
 }
 
+// `pivot_src` (may be null = pivot 0): the tensor bn_stats_kernel shifted by x[c * S]; the partial sums are then
+// sums of (x - K) and (x - K)^2.
 __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C, int slices, double count,
+                                         const float* __restrict__ pivot_src, int S,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -127,8 +134,10 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C,
         s1 += part[(size_t)c * slices + k];
         s2 += part[(size_t)(C + c) * slices + k];
     }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    const double K = pivot_src ? (double)pivot_src[(size_t)c * S] : 0.0;
+    const double dmean = s1 / count;                 // mean - K
+    const double mean = K + dmean;
+    double var = s2 / count - dmean * dmean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     save_mean[c] = (float)mean;
@@ -416,7 +425,9 @@ extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int3
     hipStream_t stream = (hipStream_t)stream_;
     int slices = bn_slices(N, C, S);
     BnWs w = bn_ws(workspace, C, slices);
+    const float* pivot_src = x;
     if (conv_partials && stat_tiles > 0) {
+        pivot_src = nullptr;        // the epilogue sums are unshifted (bias-free convolution outputs: |mean| ~ std)
         // statistics were accumulated by the producing convolution's epilogue: no pass over x
         hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
                            conv_partials + (size_t)C * stat_tiles, C, stat_tiles, w.part);
@@ -426,7 +437,7 @@ extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int3
     }
     if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
-                       slices, (double)N * S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
+                       slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
                        momentum, eps, w.scale, w.shift);
     if ((st = launch_status())) return st;
     return launch_apply(x, residual, y, N, C, S, w.scale, w.shift, fuse_relu, stream);

@@ -370,7 +370,10 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
         return false;
     if (d->Wi % 2 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
-    if (P % 2 != 0 || (long)d->Cout * P >= (1L << 30) || (long)d->Cin * P >= (1L << 30)) return false;
+    // byte offsets (4 * element index, plus tap shifts) are formed in signed 32-bit registers and the out-of-range
+    // sentinels 0xFFFFFFF0 / 0xFFFFFFFF must stay >= the descriptor's num_records: tensors of < 2^29 elements
+    // (2 GiB) only, like conv_wgrad_tring; larger ones take the direct kernel.
+    if (P % 2 != 0 || (long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
     return wino_ksplit(d, M) > 0;
 }
 

@@ -29,6 +29,8 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
 
 
@@ -77,6 +79,7 @@ class GradientSync:
         """Every replica starts from rank ``src``'s parameters and buffers."""
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
+        _lib.note_raw_write()                      # `.data` writes do not bump the version counters
 
     def _build_buckets(self, order: List[int]) -> None:
         buckets, cur, cur_bytes = [], [], 0
@@ -121,6 +124,9 @@ class GradientSync:
         if b is None:
             raise RuntimeError("a parameter that produced no gradient in the first step produced one now; "
                                "rebuild GradientSync (the live set is fixed after discovery)")
+        if b.pending <= 0:
+            raise RuntimeError("a gradient arrived for a bucket that was already reduced this step: two backward "
+                               "passes per begin_step() (gradient accumulation) are not supported")
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -163,6 +169,18 @@ class GradientSync:
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
             if lo.item() != hi.item():
                 raise RuntimeError("ranks disagree on which parameters receive gradients")
+            # every rank lays its buckets out in RANK 0's production order: a flat all-reduce of buckets built
+            # from different local orders would silently add unrelated gradients.  The live SET must agree.
+            mine = torch.tensor(order, dtype=torch.int64, device=count.device)
+            ref = mine.clone()
+            src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+            dist.broadcast(ref, src=src, group=self.group)
+            differs = torch.tensor([0 if torch.equal(torch.sort(ref)[0], torch.sort(mine)[0]) else 1],
+                                   dtype=torch.int64, device=count.device)
+            dist.all_reduce(differs, op=dist.ReduceOp.MAX, group=self.group)
+            if differs.item():
+                raise RuntimeError("ranks disagree on which parameters receive gradients (same count, different set)")
+            order = [int(i) for i in ref.tolist()]
             self._build_buckets(order)
             for b in self._buckets:                # no overlap in the discovery step
                 self._launch(b)

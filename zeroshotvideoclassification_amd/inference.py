@@ -322,14 +322,18 @@ class Fp32Engine:
         return F.normalize(self.model.output2emb_proj(pooled), dim=-1), None
 
 
-def engine_for(model: nn.Module, dtype: torch.dtype = torch.bfloat16):
-    """The model's inference engine for ``dtype`` (bf16: ``Bf16Engine``, fp32: ``Fp32Engine``), rebuilt only when a trunk parameter or BatchNorm buffer has been written
-    since it was built (tensor version counters), e.g. once per epoch for the three test sets of
-    main.py:352-358."""
+def engine_for(model: nn.Module, dtype: torch.dtype = torch.bfloat16, rebuild: bool = False):
+    """The model's inference engine for ``dtype`` (bf16: ``Bf16Engine``, fp32: ``Fp32Engine``), rebuilt only when a
+    trunk parameter or BatchNorm buffer may have been written since it was built, e.g. once per epoch for the
+    three test sets of main.py:352-358.  "Written" = the tensors' identity / version counters (torch-side
+    writes) AND ``_lib.raw_write_generation()``: the HIP BatchNorm running-statistics update, ``FusedAdam``,
+    ``load_weights`` and ``GradientSync.broadcast_state`` write through raw pointers or ``.data`` and announce
+    it there.  ``rebuild=True`` forces a rebuild (for writers this package does not know about)."""
     own = getattr(model, "module", model)
-    key = tuple(t._version for t in list(own.model.parameters()) + list(own.model.buffers()))
+    tensors = list(own.model.parameters()) + list(own.model.buffers())
+    key = (_lib.raw_write_generation(),) + tuple((id(t), t.data_ptr(), t._version) for t in tensors)
     cache = own.__dict__.setdefault("_zsv_engines", {})
-    cached = cache.get(dtype)
+    cached = None if rebuild else cache.get(dtype)
     if cached is None or cached[0] != key:
         if dtype == torch.bfloat16:
             engine = Bf16Engine(own)

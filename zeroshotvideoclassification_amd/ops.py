@@ -258,6 +258,8 @@ class _BatchNormAct(Function):
                                                       save_invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
                                                       float(momentum), float(eps), _ptr(stats), tiles, _ptr(ws), nbytes,
                                                       _stream()), "zsv_bn_fwd_train")
+                if running_mean is not None:
+                    _lib.note_raw_write()          # running statistics written behind the version counters
             else:
                 if running_mean is None or running_var is None:
                     raise RuntimeError("eval-mode BatchNorm needs running statistics")

@@ -85,4 +85,5 @@ class FusedAdam(torch.optim.Optimizer):
                            "zsv_adam_multi")
             # keep the uploaded table and any contiguous gradient copies alive until the stream is past the launch
             table.record_stream(torch.cuda.current_stream())
+            _lib.note_raw_write()                  # parameters updated through raw pointers
         return loss

@@ -54,6 +54,22 @@ def synthetic_targets(n: int, n_classes: int = 400, seed: int = 4321,
     return labels, table[labels].clone()
 
 
+def synthetic_eval_set(n: int, n_classes: int, seed: int = 77, noise: float = 0.3,
+                       broken: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """A stand-in for one test set of ``evaluate`` (main.py:224-313): class table ``(C, 300)``, labels
+    ``(n,)``, true embeddings ``(n, 300)`` and "predicted" embeddings = the true one plus Gaussian noise
+    (not normalised: the cosine distance must not depend on it), tuned so top-1 lands mid-range.  The
+    first ``broken`` labels are -1 (failed loads, auxiliary_dataset.py:502-505)."""
+    table = class_table(n_classes, seed)
+    g = _gen(seed * 31 + n_classes)
+    labels = torch.randint(0, n_classes, (n,), generator=g)
+    true = table[labels].clone()
+    pred = true * (0.5 + torch.rand(n, 1, generator=g)) + noise * torch.randn(n, EMBED_DIM, generator=g)
+    if broken:
+        labels[:broken] = -1
+    return table, labels, true, pred
+
+
 def _key_seed(key: str, seed: int) -> int:
     return (zlib.crc32(key.encode("utf-8")) << 8) ^ (seed * 0x9E3779B1)
 

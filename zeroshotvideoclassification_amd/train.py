@@ -20,9 +20,12 @@ from __future__ import annotations
 
 from typing import Iterable, Optional, Sequence, Tuple
 
+from ctypes import c_void_p
+
 import numpy as np
 import torch
-import torch.nn.functional as F
+
+from . import _lib
 
 
 _PREFIX = "module."       # nn.DataParallel's prefix in saved checkpoints (main.py:116,126,363)
@@ -38,6 +41,7 @@ def load_weights(model: torch.nn.Module, path: str) -> int:
     weights = {k[j:]: v for k, v in weights.items() if k[j:] in model_dict}
     model_dict.update(weights)
     own.load_state_dict(model_dict)
+    _lib.note_raw_write()
     return len(weights)
 
 
@@ -69,37 +73,91 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criteri
     return y.detach(), loss.detach()
 
 
-def cosine_ranking(pred: torch.Tensor, class_embed: torch.Tensor) -> torch.Tensor:
-    """argsort of scipy ``cdist(pred, class_embed, 'cosine')`` along classes (main.py:321)."""
-    sim = F.normalize(pred.float(), dim=1) @ F.normalize(class_embed.float(), dim=1).t()
-    return torch.argsort(1.0 - sim, dim=1, stable=True)
+def nearest_classes(embed_: torch.Tensor, class_embed: torch.Tensor, k: int = 5) -> torch.Tensor:
+    """``cdist(embed, class_embed, 'cosine').argsort(1)[:, :k]`` (main.py:321) on the device: double-precision
+    cosine distances on the matrix core + per-row top-k with ties by lower index (``zsv_cosine_topk``,
+    csrc/nearest_class.hip).  ``(rows, k)`` int64 class indices; HIP tensors only."""
+    if not (embed_.is_cuda and class_embed.is_cuda):
+        raise RuntimeError("nearest_classes runs on an MI355X HIP device only (no CPU fallback)")
+    e = embed_.detach().float().reshape(len(embed_), -1).contiguous()
+    c = class_embed.detach().float().contiguous()
+    if e.dim() != 2 or c.dim() != 2 or e.shape[1] != c.shape[1]:
+        raise RuntimeError(f"nearest_classes: embeddings {tuple(e.shape)} vs class table {tuple(c.shape)}")
+    rows, n_classes = int(e.shape[0]), int(c.shape[0])
+    k = min(int(k), n_classes)
+    out = torch.empty((rows, k), dtype=torch.int32, device=e.device)
+    if rows == 0:
+        return out.long()
+    lib = _lib.load()
+    nbytes = lib.zsv_cosine_topk_workspace_bytes(rows, n_classes)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=e.device)
+    with torch.cuda.device(e.device):
+        _lib.check(lib.zsv_cosine_topk(e.data_ptr(), c.data_ptr(), rows, int(e.shape[1]), n_classes, k, out.data_ptr(),
+                                       None, ws.data_ptr(), nbytes, c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "zsv_cosine_topk")
+    return out.long()
+
+
+def cosine_ranking(pred: torch.Tensor, class_embed: torch.Tensor, k: int = 5) -> torch.Tensor:
+    """The first ``k`` columns of the reference's ``cdist(...).argsort(1)`` (main.py:321)."""
+    return nearest_classes(pred, class_embed, k)
 
 
 def train_accuracy(y: torch.Tensor, class_embed: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
-    """main.py:182-185 without leaving the device."""
-    pred = cosine_ranking(y, class_embed)[:, 0]
-    return (pred == labels.to(pred.device)).float().mean() * 100.0
+    """main.py:182-185 without leaving the device: percent of samples whose nearest class embedding is
+    their label's (``cdist(Y, class_embed, 'cosine').argmin(1) == l``).  A 0-d device tensor, no host sync."""
+    pred = nearest_classes(y, class_embed.to(y.device), 1)[:, 0]
+    return (pred == labels.to(pred.device).reshape(-1)).float().mean() * 100.0
 
 
 def compute_accuracy(predicted_embed: torch.Tensor, class_embed: torch.Tensor,
                      true_embed: torch.Tensor) -> Tuple[float, float]:
     """Top-1 / top-5 accuracy (percent) to the closest class embedding (main.py:316-325)."""
     assert len(predicted_embed) == len(true_embed), "True and predicted labels must have the same number of samples"
-    order = cosine_ranking(predicted_embed, class_embed)
-    y = cosine_ranking(true_embed, class_embed)[:, 0]
-    top1 = (order[:, 0] == y).float().mean().item() * 100
-    top5 = (order[:, :5] == y[:, None]).any(dim=1).float().mean().item() * 100
+    order = nearest_classes(predicted_embed, class_embed, 5)
+    y = nearest_classes(true_embed, class_embed, 1)[:, 0]
+    n = max(len(y), 1)
+    # counts are exact integers; the reference's np.mean of booleans is the same count / n in double
+    top1 = float((order[:, 0] == y).sum().item()) / n * 100
+    top5 = float((order == y[:, None]).any(dim=1).sum().item()) / n * 100
     return top1, top5
+
+
+def _gather_rows(t: torch.Tensor, group) -> torch.Tensor:
+    """All ranks' rows of ``t`` (different counts per rank), concatenated in rank order."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    count = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    width = max(counts)
+    padded = torch.zeros((width,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[:t.shape[0]] = t
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
 
 
 @torch.no_grad()
 def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], class_embed: torch.Tensor,
-             device: Optional[torch.device] = None, splits: int = 10, dtype: Optional[torch.dtype] = None) -> dict:
+             device: Optional[torch.device] = None, splits: int = 10, dtype: Optional[torch.dtype] = None,
+             group=None, sharded: Optional[bool] = None) -> dict:
     """main.py:224-313 for one test set.  ``batches`` yields ``(X, labels, Z, ...)``; samples with
     label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248.
     ``dtype=torch.bfloat16`` runs the forward on the bf16 engine (``inference.Bf16Engine``, the
     reduced-precision eval of BASELINE config 5 / the reference's autocast, main.py:172), ``torch.float32``
-    on the folded fp32 engine (``inference.Fp32Engine``); default (None): the module's own fp32 forward."""
+    on the folded fp32 engine (``inference.Fp32Engine``); default (None): the module's own fp32 forward.
+
+    With ``torch.distributed`` initialised (one process per GPU; ``sharded`` defaults to that) every rank
+    iterates the SAME ``batches`` and runs the forward for every ``world``-th one (batch ``i`` belongs to
+    rank ``i % world``); the ``(pred, true, label)`` rows are all-gathered over ``group`` (RCCL) and every
+    rank computes the same accuracies.  The reference evaluates under one-process ``nn.DataParallel``
+    (main.py:126,250), which scatters each batch instead: same samples, same result."""
+    import torch.distributed as dist
+    if sharded is None:
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if sharded else (0, 1)
     was_training = model.training
     model.eval()
     device = device or next(model.parameters()).device
@@ -110,7 +168,9 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
     elif dtype is not None:
         raise RuntimeError(f"evaluate: dtype {dtype} is not supported (fp32 or bf16)")
     preds, trues, labels = [], [], []
-    for batch in batches:
+    for index, batch in enumerate(batches):
+        if index % world != rank:
+            continue
         x, l, z = batch[0], batch[1], batch[2]
         keep = l != -1
         if keep.sum() == 0:
@@ -122,9 +182,14 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
         trues.append(z.float().reshape(len(l), -1))
         labels.append(l.reshape(-1))
     model.train(was_training)
-    pred, true = torch.cat(preds), torch.cat(trues).to(device)
-    label = torch.cat(labels).cpu().numpy()
     class_embed = class_embed.to(device)
+    width = int(class_embed.shape[1])
+    pred = torch.cat(preds) if preds else torch.zeros((0, width), device=device)
+    true = torch.cat(trues).to(device) if trues else torch.zeros((0, width), device=device)
+    label_dev = torch.cat(labels).to(device).long() if labels else torch.zeros((0,), dtype=torch.int64, device=device)
+    if sharded:
+        pred, true, label_dev = (_gather_rows(t, group) for t in (pred, true, label_dev))
+    label = label_dev.cpu().numpy()
     acc, acc5 = compute_accuracy(pred, class_embed, true)
     out = {"accuracy": acc, "accuracy_top5": acc5, "n": int(len(pred))}
     if splits:
