@@ -244,6 +244,33 @@ typedef struct zsv_adam_tensor {
 int zsv_adam_multi(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks, float lr,
                    float beta1, float beta2, float eps, int32_t step, void* stream);
 
+/* ---- loss scaling: torch.cuda.amp.GradScaler on the device (main.py:137,195-203) ------------------ */
+/* The reference trains with `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`.
+ * The state lives in device memory so a step never waits for the host:
+ *   scale          current loss scale (GradScaler default 65536)
+ *   growth_tracker consecutive steps without a non-finite gradient
+ *   found_inf      set by zsv_grad_check_multi, consumed by zsv_adam_multi_scaled, cleared by zsv_scaler_update
+ *   steps_done     optimizer steps actually taken (skipped steps do not count): the Adam bias correction uses it */
+typedef struct zsv_scaler_state {
+    float scale;
+    int32_t growth_tracker;
+    int32_t found_inf;
+    int32_t steps_done;
+} zsv_scaler_state;
+/* found_inf |= any(!isfinite(g)) over the gradients named by an Adam table (the `g` / `n` / `first_chunk` fields;
+ * typically the flat all-reduce buckets of the data-parallel exchange): _amp_foreach_non_finite_check_and_unscale_
+ * without the write-back -- the unscale itself happens inside zsv_adam_multi_scaled. */
+int zsv_grad_check_multi(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks,
+                         zsv_scaler_state* state_device, void* stream);
+/* zsv_adam_multi with g * (1 / scale) as the gradient, skipped entirely when found_inf is set (scaler.step,
+ * main.py:200); step number = steps_done + 1 read on the device. */
+int zsv_adam_multi_scaled(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks, float lr,
+                          float beta1, float beta2, float eps, const zsv_scaler_state* state_device, void* stream);
+/* scaler.update() (main.py:203): found_inf ? scale *= backoff, tracker = 0 : (++tracker == interval ? scale *= growth,
+ * tracker = 0); steps_done += !found_inf; found_inf = 0.  GradScaler defaults: 2.0, 0.5, 2000. */
+int zsv_scaler_update(zsv_scaler_state* state_device, float growth_factor, float backoff_factor,
+                      int32_t growth_interval, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

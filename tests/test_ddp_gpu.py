@@ -65,6 +65,27 @@ def _worker(rank, world, port):
                 err = (g.grad - ref[k]).abs().max().item()
                 assert err <= 1e-6 * (ref[k].abs().max().item() + 1e-12), (step, k, err)
         assert len(sync.bucket_sizes) >= 2 and sync.bytes_reduced_last_step == sum(sync.bucket_sizes) * 4
+
+        # Adam straight from the all-reduce buckets under the device-side loss scaler
+        # (main.py:195-203): every rank applies the same update, .grad stay views of the reduced buffers
+        from zeroshotvideoclassification_amd import optim
+        model.load_state_dict(state0)
+        fused = optim.FusedAdam(model.parameters(), lr=1e-3, grad_buckets=sync)
+        scaler = optim.LossScaler(init_scale=128.0)
+        for step in range(2):
+            train.train_step(model, fused, crit, x, z, sync, scaler)
+        torch.cuda.synchronize()
+        assert fused._static is not None
+        for flat, rows in sync.bucket_layout():
+            for p, off in rows:
+                assert p.grad.data_ptr() == flat.data_ptr() + 4 * off
+        for k, p in model.named_parameters():
+            lo, hi = p.detach().clone(), p.detach().clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), k                                   # replicas stay bit-identical
+        moved = (model.output2emb_proj.layers[1].weight.detach() - state0["output2emb_proj.layers.1.weight"]).abs().max().item()
+        assert 1e-4 < moved < 1e-2 and scaler.state()["steps_done"] == 2
         dist.barrier()
     finally:
         dist.destroy_process_group()

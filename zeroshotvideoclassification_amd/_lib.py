@@ -75,6 +75,9 @@ SIGNATURES = {
     "zsv_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "zsv_cosine_topk": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
     "zsv_adam_multi": (c_int, [_P, c_int32, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
+    "zsv_grad_check_multi": (c_int, [_P, c_int32, c_int64, _P, _P]),
+    "zsv_adam_multi_scaled": (c_int, [_P, c_int32, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
+    "zsv_scaler_update": (c_int, [_P, c_float, c_float, c_int32, _P]),
     "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
 }
 

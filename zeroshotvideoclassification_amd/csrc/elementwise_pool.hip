@@ -344,6 +344,106 @@ extern "C" int zsv_adam_multi(const zsv_adam_tensor* table_device, int32_t count
     return launch_status();
 }
 
+// ---- loss scaling (torch.cuda.amp.GradScaler, main.py:137,195-203) on the device -----------------------
+// scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update() without a host round trip:
+//   grad_check_multi : found_inf |= any non-finite scaled gradient   (_amp_foreach_non_finite_check_and_unscale_)
+//   adam_multi_scaled: skipped when found_inf; gradients multiplied by 1/scale in registers; the bias correction
+//                      uses the device-side count of steps actually taken
+//   scaler_update    : _amp_update_scale_ (backoff / growth) + steps_done += !found_inf, found_inf = 0
+namespace zsv {
+__global__ __launch_bounds__(256) void grad_check_multi_kernel(const zsv_adam_tensor* __restrict__ table, int count,
+                                                               zsv_scaler_state* __restrict__ st) {
+    int lo = 0, hi = count - 1;
+    const long chunk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const zsv_adam_tensor t = table[lo];
+    const long base = (chunk - t.first_chunk) * ADAM_CHUNK;
+    const long end = min(t.n, base + ADAM_CHUNK);
+    bool bad = false;
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+        const float g = t.g[i];
+        bad |= !(fabsf(g) <= 3.402823466e38f);                    // inf or NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) st->found_inf = 1;   // benign race: every writer stores 1
+}
+
+__global__ __launch_bounds__(256) void adam_multi_scaled_kernel(const zsv_adam_tensor* __restrict__ table, int count, float lr,
+                                                                float b1, float b2, float eps,
+                                                                const zsv_scaler_state* __restrict__ st) {
+    if (st->found_inf) return;                                     // scaler.step skips optimizer.step (main.py:200)
+    const float inv_scale = (float)(1.0 / (double)st->scale);      // as GradScaler: scale.double().reciprocal().float()
+    const int step = st->steps_done + 1;
+    const float step_size = (float)((double)lr / (1.0 - pow((double)b1, (double)step)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, (double)step)));
+    int lo = 0, hi = count - 1;
+    const long chunk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1;
+    }
+    const zsv_adam_tensor t = table[lo];
+    const long base = (chunk - t.first_chunk) * ADAM_CHUNK;
+    const long end = min(t.n, base + ADAM_CHUNK);
+    for (long i = base + threadIdx.x; i < end; i += 256) {
+        const float gi = t.g[i] * inv_scale;
+        const float mi = b1 * t.exp_avg[i] + (1.f - b1) * gi;
+        const float vi = b2 * t.exp_avg_sq[i] + (1.f - b2) * gi * gi;
+        t.exp_avg[i] = mi;
+        t.exp_avg_sq[i] = vi;
+        t.p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+__global__ void scaler_update_kernel(zsv_scaler_state* st, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->found_inf) {
+        st->scale *= backoff;
+        st->growth_tracker = 0;
+    } else {
+        const int ok = st->growth_tracker + 1;
+        if (ok == interval) {
+            const float grown = st->scale * growth;
+            if (fabsf(grown) <= 3.402823466e38f) st->scale = grown;   // torch keeps the old scale if growth overflows
+            st->growth_tracker = 0;
+        } else {
+            st->growth_tracker = ok;
+        }
+        st->steps_done += 1;
+    }
+    st->found_inf = 0;
+}
+}  // namespace zsv
+
+extern "C" int zsv_grad_check_multi(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks,
+                                    zsv_scaler_state* state_device, void* stream) {
+    if (!table_device || !state_device) return ZSV_E_NULL;
+    if (count <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffL) return count == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    hipLaunchKernelGGL(zsv::grad_check_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table_device,
+                       count, state_device);
+    return launch_status();
+}
+
+extern "C" int zsv_adam_multi_scaled(const zsv_adam_tensor* table_device, int32_t count, int64_t total_chunks, float lr,
+                                     float beta1, float beta2, float eps, const zsv_scaler_state* state_device, void* stream) {
+    if (!table_device || !state_device) return ZSV_E_NULL;
+    if (count <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffL) return count == 0 ? ZSV_OK : ZSV_E_BAD_SHAPE;
+    hipLaunchKernelGGL(zsv::adam_multi_scaled_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, table_device,
+                       count, lr, beta1, beta2, eps, state_device);
+    return launch_status();
+}
+
+extern "C" int zsv_scaler_update(zsv_scaler_state* state_device, float growth_factor, float backoff_factor,
+                                 int32_t growth_interval, void* stream) {
+    if (!state_device) return ZSV_E_NULL;
+    if (!(growth_factor > 1.f) || !(backoff_factor > 0.f && backoff_factor < 1.f) || growth_interval <= 0) return ZSV_E_BAD_SHAPE;
+    hipLaunchKernelGGL(zsv::scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_device, growth_factor,
+                       backoff_factor, growth_interval);
+    return launch_status();
+}
+
 extern "C" const char* zsv_status_string(int status) {
     switch (status) {
         case ZSV_OK: return "ok";

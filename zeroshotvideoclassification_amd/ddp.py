@@ -19,6 +19,11 @@ gradients (126.9 MB fp32), issued bucket by bucket while backward is still runni
   waits for them;
 * BatchNorm statistics stay per replica, as under DataParallel.
 
+After ``finish_step()`` every live parameter's ``.grad`` IS a view of its bucket (the averaged values are not
+copied back), so ``optim.FusedAdam(..., grad_buckets=sync)`` walks the all-reduce buffers themselves with a
+descriptor table built once, and ``torch.optim.Adam`` sees ordinary ``.grad`` tensors.
+``GradientSync(model, local=True)`` keeps the bucketing without any collective (one process, one GPU).
+
 With equal shards, the mean over ranks of per-rank mean-MSE gradients equals the full-batch
 mean-MSE gradient DataParallel computes.  Works on CPU tensors with the gloo backend (tests).
 """
@@ -53,11 +58,13 @@ class GradientSync:
     """Bucketed, backward-overlapped gradient averaging for one model replica."""
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_bytes: int = DEFAULT_BUCKET_BYTES,
-                 broadcast_initial_state: bool = True):
-        if not dist.is_initialized():
+                 broadcast_initial_state: bool = True, local: bool = False):
+        self.local = bool(local)
+        if not self.local and not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU; init_process_group first)")
         self.group = process_group
-        self.world = dist.get_world_size(process_group)
+        self.world = 1 if self.local else dist.get_world_size(process_group)
+        self.layout_version = 0                  # bumped whenever the buckets are (re)built
         self.model = model
         self.bucket_bytes = int(bucket_bytes)
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -95,6 +102,23 @@ class GradientSync:
             buckets.append(_Bucket(cur))
         self._buckets = buckets
         self._bucket_of = {id(p): b for b in buckets for p in b.params}
+        self.layout_version += 1
+
+    @property
+    def ready(self) -> bool:
+        """True once the discovery step has fixed the live set and the bucket layout."""
+        return self._buckets is not None
+
+    def bucket_layout(self):
+        """``[(flat buffer, [(parameter, element offset), ...]), ...]`` in production order."""
+        out = []
+        for b in self._buckets or []:
+            off, rows = 0, []
+            for p in b.params:
+                rows.append((p, off))
+                off += p.numel()
+            out.append((b.flat, rows))
+        return out
 
     @property
     def live_parameter_count(self) -> int:
@@ -133,6 +157,8 @@ class GradientSync:
 
     @torch.no_grad()
     def _launch(self, b: _Bucket) -> None:
+        """Pack the bucket's gradients into its flat buffer, sum over ranks, scale by 1/world -- on the side
+        stream.  Nothing is copied back: ``finish_step`` points each ``.grad`` at its slice of the buffer."""
         grads = [p.grad for p in b.params]
         scale = 1.0 / self.world
         if self._cuda:
@@ -141,17 +167,17 @@ class GradientSync:
             self._side.wait_event(ready)
             with torch.cuda.stream(self._side):
                 torch._foreach_copy_(b.views, grads)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                b.work.wait()                     # orders the side stream after RCCL; host does not block
-                b.flat.mul_(scale)
-                torch._foreach_copy_(grads, b.views)
-                for g in grads:                   # the side stream uses memory owned by the autograd stream
+                if self.world > 1:
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b.work.wait()                 # orders the side stream after RCCL; host does not block
+                    b.flat.mul_(scale)
+                for g in grads:                   # the side stream reads memory owned by the autograd stream
                     g.record_stream(self._side)
         else:
             torch._foreach_copy_(b.views, grads)
-            dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-            b.flat.mul_(scale)
-            torch._foreach_copy_(grads, b.views)
+            if self.world > 1:
+                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                b.flat.mul_(scale)
         self.bytes_reduced_last_step += b.numel * b.flat.element_size()
 
     def finish_step(self) -> None:
@@ -163,6 +189,12 @@ class GradientSync:
             # first step: the live set and the production order are now known.  Ranks must agree
             # on them (same model, same graph) -- checked cheaply through the count.
             order = list(self._arrival)
+            if self.local:
+                self._build_buckets(order)
+                for b in self._buckets:
+                    self._launch(b)
+                self._adopt_bucket_views()
+                return
             count = torch.tensor([len(order)], dtype=torch.int64, device=self.params[0].device)
             lo, hi = count.clone(), count.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
@@ -189,8 +221,15 @@ class GradientSync:
             if late:
                 missing = sum(b.pending for b in late)
                 raise RuntimeError(f"{missing} live parameters produced no gradient this step")
+        self._adopt_bucket_views()
+
+    def _adopt_bucket_views(self) -> None:
         if self._cuda:
             torch.cuda.current_stream().wait_stream(self._side)
+        for b in self._buckets:
+            for p, v in zip(b.params, b.views):
+                if p.grad is not v:
+                    p.grad = v                    # the averaged gradient lives in the bucket; no copy back
 
     def remove(self) -> None:
         for h in self._hooks:

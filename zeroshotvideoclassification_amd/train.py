@@ -58,18 +58,26 @@ def embed(model: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion, x: torch.Tensor,
-               z: torch.Tensor, grad_sync=None) -> Tuple[torch.Tensor, torch.Tensor]:
+               z: torch.Tensor, grad_sync=None, scaler=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """One iteration of main.py:170-203.  ``grad_sync`` (a ``ddp.GradientSync``) all-reduces the
-    gradients across ranks, overlapped with backward, before the optimizer step."""
+    gradients across ranks, overlapped with backward, before the optimizer step.  ``scaler`` (an
+    ``optim.LossScaler`` or a ``torch.cuda.amp.GradScaler``) reproduces main.py:195-203:
+    ``scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`` -- a non-finite gradient skips
+    the update and halves the scale.  (The reference's fp16 autocast forward, main.py:172, is not reproduced:
+    the training forward stays fp32, where the scaler only ever sees finite gradients unless the loss blows up.)"""
     optimizer.zero_grad(set_to_none=True)
     if grad_sync is not None:
         grad_sync.begin_step()
     y = embed(model, x)
     loss = criterion(y, z)
-    loss.backward()
+    (scaler.scale(loss) if scaler is not None else loss).backward()
     if grad_sync is not None:
         grad_sync.finish_step()
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
     return y.detach(), loss.detach()
 
 
@@ -79,8 +87,8 @@ def nearest_classes(embed_: torch.Tensor, class_embed: torch.Tensor, k: int = 5)
     csrc/nearest_class.hip).  ``(rows, k)`` int64 class indices; HIP tensors only."""
     if not (embed_.is_cuda and class_embed.is_cuda):
         raise RuntimeError("nearest_classes runs on an MI355X HIP device only (no CPU fallback)")
-    e = embed_.detach().float().reshape(len(embed_), -1).contiguous()
     c = class_embed.detach().float().contiguous()
+    e = embed_.detach().float().reshape(len(embed_), c.shape[-1] if c.dim() == 2 else -1).contiguous()
     if e.dim() != 2 or c.dim() != 2 or e.shape[1] != c.shape[1]:
         raise RuntimeError(f"nearest_classes: embeddings {tuple(e.shape)} vs class table {tuple(c.shape)}")
     rows, n_classes = int(e.shape[0]), int(c.shape[0])
