@@ -305,7 +305,7 @@ def test_full_size_gradients_match_the_oracle_per_parameter(net, n, train_mode):
         assert sorted(got) == sorted(ref)                                   # same live / dead split
         worst = max((rel_l2(got[k], ref[k]), k) for k in ref)
         assert worst[0] < tol, (str(dtype), worst)
-    assert len(got) == (113 if net == "r2plus1d_18" else 20)
+    assert len(got) == (115 if net == "r2plus1d_18" else 20)          # 115 of 193 (R(2+1)D-18 + head), 20 of 24 (fc7 / fc8 unused)
 
 
 def test_mc3_18_trunk_matches_oracle_trunk():
