@@ -13,10 +13,10 @@ with backward.  Inputs are resident in HBM before the timed region.  Rank 0 prin
 line.  Extra objects on that line:
 
 * ``roofline``  : the dominant kernel (the fp32-MFMA convolution on the 64->144 1x3x3 shape,
-  41 % of forward FLOPs; kw taps in Winograd F(2,3) form): algorithmic (direct-convolution)
+  41 % of forward FLOPs; kw taps in Winograd F(4,3) form): algorithmic (direct-convolution)
   FLOPs per launch / mean launch duration from HIP events recorded on the launch stream inside
   the timed steps, against the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md); the FLOPs
-  the matrix pipe really executes (2/3 of them) are reported next to it;
+  the matrix pipe really executes (1/2 of them) are reported next to it;
 * ``cpu_baseline``: the CPU oracle (oracle/restatement.py, pinned to the reference) timed on
   this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only.
 """
@@ -46,11 +46,11 @@ FP32_MFMA_PEAK_TFLOPS = 157.3
 S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56)
 # the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step
 DOMINANT = {
-    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino_kernel<3, 12, true>",
+    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino4_kernel<3, 12>",
                         what="Conv3d(64,144,(1,3,3)) forward @16x56x56 (resnet.py:40-45, layer1 spatial half of Conv2Plus1D)"),
     # network.py:105 conv2 = Conv3d(64,128,3x3x3, pad 1) after pool1 (1,2,2): 22.2 GFLOP/clip, 29 % of C3D's forward FLOPs
     "c3d": dict(geometry=dict(Cin=64, Cout=128, kT=3, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56), launches=1,
-                symbol="zsv::conv_wino_kernel<4, 0, true>",
+                symbol="zsv::conv_wino4_kernel<4, 0>",
                 what="Conv3d(64,128,3x3x3) forward @16x56x56 (network.py:105 conv2)"),
 }
 BASELINE_CONFIG = {"r2plus1d_18": "BASELINE.json configs[1]; configs[2] when n_gpus > 1", "c3d": "BASELINE.json configs[3]"}
@@ -324,15 +324,15 @@ def main():
             flops = 2.0 * n * gm["Cout"] * gm["Cin"] * taps * voxels   # direct-convolution count (S1: 8.324 GFLOP/clip)
             alg_bytes = 4.0 * (n * gm["Cin"] * voxels + n * gm["Cout"] * voxels + gm["Cout"] * gm["Cin"] * taps)
             achieved = flops / (mean_ms * 1e-3) / 1e12
-            # the kernel computes the kw taps in Winograd F(2,3) form: 4 multiplies per output pair instead of 6,
-            # so the matrix pipe executes 2/3 of the algorithmic FLOPs (counter-checked: profiles/*_mfma_busy.json)
-            executed = flops * 2.0 / 3.0 / (mean_ms * 1e-3) / 1e12
+            # the kernel computes the kw taps in Winograd F(4,3) form (W % 4 == 0): 6 multiplies per 4 outputs instead of
+            # 12, so the matrix pipe executes 1/2 of the algorithmic FLOPs (counter-checked: profiles/*_mfma_busy.json)
+            executed = flops * 0.5 / (mean_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": f"{dom['symbol']} = {dom['what']} "
-                                         f"(fp32 Winograd F(2,3) along W + its weight-transform launch), {dom['launches']} launch(es)/step",
+                                         f"(fp32 Winograd F(4,3) along W + its weight-transform launch), {dom['launches']} launch(es)/step",
                                "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                                "achieved_is": "ALGORITHMIC (direct-convolution) FLOPs / time, as SURVEY 8d counts them; this is not "
-                                              "pipe utilisation: the Winograd form executes 2/3 of them -> mfma_executed_frac",
+                                              "pipe utilisation: the Winograd form executes 1/2 of them -> mfma_executed_frac",
                                "mfma_executed_tflops": round(executed, 2),
                                "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                                "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),

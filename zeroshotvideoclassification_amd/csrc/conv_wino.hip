@@ -39,7 +39,7 @@ struct WinoParams {
     int S, HW, W, H, T;     // voxels per clip / frame, row length, rows, frames
     int kT, R;              // temporal taps (1 or 3, pad kT/2), row taps R = 3*kT (a row tap = one (kt, kh))
     int P;                  // N * S
-    unsigned in_bytes;
+    unsigned in_bytes, u_bytes;   // bytes of the input tensor / of the transformed-weight array
     int tiles_m, tiles_n;
     int ksplit, chunks_per_split;   // > 1: K is cut into parts, part s writes its raw partial result to OUT + s * slab_elems
     long slab_elems;
@@ -339,6 +339,268 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 #endif
 }
 
+// ================================================================================================
+// F(4,3) form of the same convolution, for W % 4 == 0: four adjacent outputs along W share six inputs d0..d5 =
+// in[w-1..w+4] of one (c, row tap) row; with g0..g2 the kw weights
+//     V0 = 4d0 - 5d2 + d4     V1 = (d3 + d4) - 4(d1 + d2)   V2 = (d4 - d3) + 4(d1 - d2)
+//     V3 = (d4 - d2) + 2(d3 - d1)   V4 = (d4 - d2) - 2(d3 - d1)   V5 = 4d1 - 5d3 + d5
+//     U0 = g0/4   U1 = -(g0+g1+g2)/6   U2 = -(g0-g1+g2)/6   U3 = g0/24 + g1/12 + g2/6   U4 = g0/24 - g1/12 + g2/6   U5 = g2
+//     y(w) = M0+M1+M2+M3+M4   y(w+1) = (M1-M2) + 2(M3-M4)   y(w+2) = (M1+M2) + 4(M3+M4)   y(w+3) = (M1-M2) + 8(M3-M4) + M5
+// 6 multiplies per 4 outputs instead of 12: 2x fewer MFMAs than the direct form (F(2,3): 1.5x), still fp32 in / fp32
+// accumulate.  The transforms' constants cost accuracy: measured max error 1.1e-6 of the output range against 4e-7 for the
+// direct and the F(2,3) forms (K = 576), tested at 1e-5.
+// Shape: rows = 16*TM output channels, columns = 64 voxel QUADS per workgroup (one 16-quad block per wave = the same 256
+// consecutive voxels as above), K = (16-channel block, row tap); per chunk the six U panels [rows][16 k] and one raw image
+// [16][256 + 2 halo] arrive by LDS-DMA exactly as above.  A lane reads (d1..d4) as one aligned ds_read_b128 plus d0, d5.
+// With 64 rows the two stages of U panels do not fit twice per CU (2 x 82 KB), so there the U panel is single-buffered:
+// a second barrier per chunk separates the fragment reads of a chunk from the DMAs of the next one.
+__global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
+                                                         int C, int nblk, int R, long sm, long sc, int flip, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c16 = (int)(i % 16);
+        long r = i / 16;
+        const int m = (int)(r % Mp);
+        r /= Mp;
+        const int pt = (int)(r % 6);
+        r /= 6;
+        const int kh = (int)(r % R);
+        const int cb = (int)(r / R);
+        const int c = cb * 16 + c16;
+        float v = 0.f;
+        if (m < M && c < C) {
+            const float* g = W + (size_t)m * sm + (size_t)c * sc;
+            const int last = 3 * R - 1;
+            const int k0 = flip ? last - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? last - (3 * kh + 1) : 3 * kh + 1,
+                      k2 = flip ? last - (3 * kh + 2) : 3 * kh + 2;
+            const double g0 = g[k0], g1 = g[k1], g2 = g[k2];          // (formed in double, rounded once)
+            const double u = pt == 0 ? g0 / 4 : pt == 1 ? -((g0 + g2) + g1) / 6 : pt == 2 ? -((g0 + g2) - g1) / 6
+                           : pt == 3 ? (g0 / 24 + g2 / 6) + g1 / 12 : pt == 4 ? (g0 / 24 + g2 / 6) - g1 / 12 : g2;
+            v = (float)u;
+        }
+        Up[i] = v;
+    }
+}
+
+template <int TM, int NCHUNKS>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, const float* __restrict__ Up,
+                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 16 * TM, BN = 256, BK = 16, NP = 6;
+    constexpr bool USINGLE = TM >= 4;
+    constexpr int LDB = 264, C0 = 4;           // image row: left halo at column 3, the 256 voxels at 4..259, right halo at 260
+    constexpr int A_FLOATS = NP * BM * BK, B_FLOATS = BK * LDB;
+    constexpr int IMG = B_FLOATS + 64;         // image + 64 floats of scratch where the halo DMA lands
+    constexpr int STAGE = A_FLOATS + IMG;
+    constexpr unsigned OOB = 0xFFFFFFFFu, OOB16 = 0xFFFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float pool[];
+    auto u_of = [&](int buf) -> float* { return pool + (USINGLE ? 0 : buf * STAGE); };
+    auto img_of = [&](int buf) -> float* { return pool + (USINGLE ? A_FLOATS + buf * IMG : buf * STAGE + A_FLOATS); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lid = xcd_tile(gridDim.x, blockIdx.x);
+    const int split = lid % prm.ksplit, tile = lid / prm.ksplit;
+    const int m0 = (tile % prm.tiles_m) * BM;
+    const int n0 = (tile / prm.tiles_m) * BN;
+    if (prm.ksplit > 1) OUT += (size_t)split * prm.slab_elems;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
+    const int ch_bytes = 4 * prm.S;
+    auto decode = [&](int p, int& base_bytes, unsigned& hmask) {
+        base_bytes = 0;
+        hmask = 0;
+        if (p >= 0 && p < prm.P) {
+            const int n = p / prm.S;
+            int r = p - n * prm.S;
+            const int t = r / prm.HW;
+            r -= t * prm.HW;
+            const int h = r / prm.W;
+            base_bytes = 4 * (n * prm.C * prm.S + (p - n * prm.S));
+            for (int kt = 0; kt < prm.kT; ++kt)
+                for (int kh = 0; kh < 3; ++kh)
+                    hmask |= (unsigned)((unsigned)(h + kh - 1) < (unsigned)prm.H && (unsigned)(t + kt - prm.kT / 2) < (unsigned)prm.T) << (kt * 3 + kh);
+        }
+    };
+    int base_bytes;
+    unsigned hmask;
+    decode(n0 + 4 * lane, base_bytes, hmask);             // this lane's 16-byte piece of every k row (W % 4 == 0: one row, one bit)
+    int halo_base = 0;
+    unsigned halo_mask = 0;
+    if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
+
+    // U panels: 6*TM pieces of 16 rows x 64 B, piece q = wave + 4*j = (point q / TM, row block q % TM)
+    constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Up), 0, prm.u_bytes, 0x00020000);
+    const int u_lane_bytes = 4 * ((m0 + (lane >> 2)) * 16 + ((lane & 3) ^ ((((lane >> 2) >> 2) & 1) << 1)) * 4);
+    const int u_chunk_bytes = 4 * NP * BK * prm.Mp;
+
+    const int nchunks_all = NCHUNKS > 0 ? NCHUNKS : prm.nblk * prm.R;
+    const int c_first = NCHUNKS > 0 ? 0 : split * prm.chunks_per_split;
+    const int nchunks = NCHUNKS > 0 ? NCHUNKS : min(prm.chunks_per_split, nchunks_all - c_first);
+    int ld_cb = c_first / prm.R, ld_kt = (c_first % prm.R) / 3, ld_kh = c_first % 3;
+    // the DMAs of chunk `chunk` into stage `buf`: 4 image pieces (k rows 4*wave .. +3), the halo (wave 0), this wave's U pieces
+    auto issue = [&](int chunk, int buf) {
+        float* us = u_of(buf);
+        float* bs = img_of(buf);
+        const int toff = 4 * ((ld_kh - 1) * prm.W + (ld_kt - prm.kT / 2) * prm.HW);
+        const int ld_r = ld_kt * 3 + ld_kh;
+        const unsigned ok = (hmask >> ld_r) & 1u;
+        const int ci0 = ld_cb * 16;
+        const unsigned voff = ok ? (unsigned)(base_bytes + toff) : OOB16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0), 16, (int)(ci < prm.C ? voff : OOB16),
+                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+        }
+        if (wave == 0) {
+            const int k = lane >> 1;
+            const int ci = ci0 + k;
+            const unsigned hok = (halo_mask >> ld_r) & 1u;
+            unsigned hv = (unsigned)(halo_base + toff) | (hok - 1u);
+            if (lane >= 32 || ci >= prm.C) hv = OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + B_FLOATS), 4, (int)(hv + (hv == OOB ? 0u : (unsigned)(ci * ch_bytes))), 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int piece = wave + 4 * j;
+            if (piece < NPIECES) {
+                const int pt = piece / TM, ib = piece % TM;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_ptr_t)(us + 256 * piece), 16, u_lane_bytes,
+                                                         chunk * u_chunk_bytes + 4 * 16 * (pt * prm.Mp + 16 * ib), 0, 0);
+            }
+        }
+        if (++ld_kh == 3) {
+            ld_kh = 0;
+            if (++ld_kt == prm.kT) { ld_kt = 0; ++ld_cb; }
+        }
+    };
+    auto place_halo = [&](int buf) {
+        if (wave == 0 && lane < 32) {
+            float* bs = img_of(buf);
+            const float v = bs[B_FLOATS + lane];
+            bs[(lane >> 1) * LDB + ((lane & 1) ? C0 + BN : C0 - 1)] = v;
+        }
+    };
+
+    f32x4 acc[NP][TM];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    const int v_first = n0 + 64 * wave + 4 * r16;                  // first voxel of this lane's quad
+    const bool zero_d0 = v_first % prm.W == 0, zero_d5 = v_first % prm.W + 4 >= prm.W;
+    const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
+
+    issue(c_first, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    place_halo(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (!USINGLE && ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
+        const float* as = u_of(cur);
+        const float* bs = img_of(cur);
+        f32x4 a4[NP][TM];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
+        float dl[2], dr[2];
+        f32x4 dm[2];
+        auto fetch = [&](int s, int slot) {
+            const float* src = bs + (4 * g + s) * LDB + C0 + 64 * wave + 4 * r16;        // image column of d1
+            dl[slot] = src[-1];
+            dm[slot] = *reinterpret_cast<const f32x4*>(src);
+            dr[slot] = src[4];
+        };
+        fetch(0, 0);
+        if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
+            __syncthreads();
+            if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sl = s & 1;
+            const float d0 = zero_d0 ? 0.f : dl[sl], d1 = dm[sl][0], d2 = dm[sl][1], d3 = dm[sl][2], d4 = dm[sl][3],
+                        d5 = zero_d5 ? 0.f : dr[sl];
+            float v[NP];
+            const float t12 = d1 + d2, t34 = d3 + d4, u12 = d1 - d2, u43 = d4 - d3, u42 = d4 - d2, u31 = d3 - d1;
+            v[0] = __fmaf_rn(4.f, d0, __fmaf_rn(-5.f, d2, d4));
+            v[1] = __fmaf_rn(-4.f, t12, t34);
+            v[2] = __fmaf_rn(4.f, u12, u43);
+            v[3] = __fmaf_rn(2.f, u31, u42);
+            v[4] = __fmaf_rn(-2.f, u31, u42);
+            v[5] = __fmaf_rn(4.f, d1, __fmaf_rn(-5.f, d3, d5));
+            if (s < 3) fetch(s + 1, sl ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ch + 1 < nchunks) place_halo(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- output transform (+ statistics) (+ add, bias, ReLU) + 16-byte stores: lane holds rows 4g..4g+3 of quad column r16
+    const bool stats = prm.stat_sum != nullptr;
+    float* red = pool;                                   // [4 waves][BM][2] partial sums (the staging LDS is free now)
+    if (stats) __syncthreads();
+    const bool quad_ok = v_first < prm.P;
+    const int n_clip = v_first / prm.S;
+    const int quad_off = n_clip * prm.M * prm.S + (v_first - n_clip * prm.S);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * i + 4 * g + r;
+            const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
+            const float s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
+            f32x4 y = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
+            float s1 = 0.f, s2 = 0.f;
+            if (quad_ok && m < prm.M) {
+                s1 = (y[0] + y[1]) + (y[2] + y[3]);
+                s2 = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+                const int off = quad_off + m * prm.S;
+                if (prm.add != nullptr) y += *reinterpret_cast<const f32x4*>(prm.add + off);
+                if (prm.bias != nullptr) y += prm.bias[m];
+                if (prm.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+                *reinterpret_cast<f32x4*>(OUT + off) = y;
+            }
+            if (stats) {                                  // 16 lanes (r16) share row m
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (r16 == 0) {
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2] = s1;
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < prm.M) {               // the 4 waves' partials, in wave order
+            const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
+            const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
+            const int tn = n0 / BN;
+            prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + tn] = t1;
+            prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + tn] = t2;
+        }
+    }
+#endif
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -382,15 +644,17 @@ bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->
 bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
 int wino_fwd_stat_tiles(const zsv_conv_desc* d) { return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256); }
 
-static size_t wino_bytes(int M, int C, int kT) {
-    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
-    return wino_align((size_t)nblk * 3 * kT * 4 * 16 * Mp * sizeof(float));
+// W % 4 == 0: the F(4,3) kernel (6 Winograd points), else F(2,3) (4 points)
+static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_F43") == nullptr; }
+static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
+    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16, points = wino_f43(d) ? 6 : 4;
+    return wino_align((size_t)nblk * 3 * d->kT * points * 16 * Mp * sizeof(float));
 }
 // transformed weights + (split-K) the parts' slabs
 static size_t wino_total_bytes(const zsv_conv_desc* d, int M, int C) {
     const int ks = wino_ksplit(d, M);
     const size_t out_bytes = (size_t)d->N * M * d->Ti * d->Hi * d->Wi * sizeof(float);
-    return wino_bytes(M, C, d->kT) + (ks > 1 ? (size_t)ks * out_bytes : 0);
+    return wino_bytes(d, M, C) + (ks > 1 ? (size_t)ks * out_bytes : 0);
 }
 size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d) { return wino_total_bytes(d, d->Cin, d->Cout); }
 size_t wino_fwd_workspace_bytes(const zsv_conv_desc* d) { return wino_total_bytes(d, d->Cout, d->Cin); }
@@ -405,6 +669,17 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
     hipLaunchKernelGGL((conv_wino_kernel<TM, NCHUNKS, X4>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    return launch_status();
+}
+
+template <int TM, int NCHUNKS>
+static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 264 + 64;                           // as in the kernel
+    constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
+    hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
 
@@ -434,17 +709,22 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     p.chunks_per_split = (p.nblk * p.R + ks - 1) / ks;
     p.slab_elems = (long)d->N * M * p.S;
     float* up = (float*)workspace;
-    float* slabs = (float*)((char*)workspace + wino_bytes(M, C, d->kT));
+    float* slabs = (float*)((char*)workspace + wino_bytes(d, M, C));
     if (ks > 1) { p.bias = nullptr; p.relu = 0; out = slabs; }         // bias / ReLU move to the ordered sum of the parts
-    const long total = (long)p.nblk * p.R * 4 * 16 * p.Mp;
+    const bool f43 = wino_f43(d);
+    p.u_bytes = (unsigned)wino_bytes(d, M, C);
+    const long total = (long)p.nblk * p.R * (f43 ? 6 : 4) * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, p.R, sm, sc, flip,
-                       total);
+    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C,
+                       p.nblk, p.R, sm, sc, flip, total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const bool x4 = d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_X4") == nullptr;
     int st;
-    if (tm == 3) {
+    if (f43) {
+        if (tm == 3) st = (p.nblk * p.R == 12 && ks == 1) ? wino4_launch<3, 12>(p, up, in, out, stream) : wino4_launch<3, 0>(p, up, in, out, stream);
+        else st = wino4_launch<4, 0>(p, up, in, out, stream);
+    } else if (tm == 3) {
         if (x4) st = (p.nblk * p.R == 12 && ks == 1) ? wino_launch<3, 12, true>(p, up, in, out, stream) : wino_launch<3, 0, true>(p, up, in, out, stream);
         else st = wino_launch<3, 0, false>(p, up, in, out, stream);
     } else {
