@@ -151,13 +151,13 @@ def usable_cores() -> int:
 
 def pmc_traffic(n_clips: int):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_s1_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of
+    (profiles/r02_s1_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of
     tools/conv_bench.py at N = 22).  Counters cannot be read inside this process; None when the
     batch differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_s1_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_s1_hbm_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"]["conv_wino_kernel<3, 12>"]
+            k = json.load(f)["kernels"]["conv_wino4_kernel<3, 12>"]
         return round(k["hbm_bytes"]) if n_clips == CLIPS_PER_GPU else None
     except Exception:
         return None
