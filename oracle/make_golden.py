@@ -281,12 +281,60 @@ def run_accuracy():
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# module surface that no factory / get_network reaches: Bottleneck (resnet.py:116-162), ResNet18 head (network.py:50-80)
+def run_surface_extras():
+    """The reference's own ``Bottleneck`` blocks inside ``VideoResNet`` (one per stage, (2+1)D convolutions) and the
+    original ``ResNet18`` single-Linear head, on name-keyed weights and seeded clips: forward (train-mode BatchNorm for the
+    trunk; eval for the head, whose dropout is RNG-dependent) + the fp64 gradient norms of every parameter."""
+    ref_network, ref_resnet = import_reference()
+    out = {}
+    x = S.synthetic_clips(2, 4, 32, seed=21)
+
+    def grads64(build, run, mode_train):
+        m = build().double()
+        m.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in weights.items()})
+        m.train(mode_train)
+        y = run(m, x.double())
+        (y * y).sum().backward()
+        names = [k for k, p in m.named_parameters() if p.grad is not None]
+        return y.detach().numpy(), np.array(names), np.array([dict(m.named_parameters())[k].grad.norm().item() for k in names])
+
+    def bottleneck_trunk():
+        return ref_resnet.VideoResNet(block=ref_resnet.Bottleneck, conv_makers=[ref_resnet.Conv2Plus1D] * 4, layers=[1, 1, 1, 1],
+                                      stem=ref_resnet.R2Plus1dStem)
+    torch.manual_seed(0)
+    m = bottleneck_trunk()
+    weights = S.keyed_state_dict(m.state_dict(), seed=3, bn_jitter=True)
+    m.load_state_dict(weights)
+    m.train()
+    pooled, f = m(x.reshape(2, 3, 4, 32, 32))
+    out["bottleneck_keys"] = np.array(list(m.state_dict().keys()))
+    out["bottleneck_pooled_f32"] = pooled.detach().numpy()
+    out["bottleneck_feature_shape"] = np.array(f.shape)
+    y64, names, norms = grads64(bottleneck_trunk, lambda mod, xx: mod(xx.reshape(2, 3, 4, 32, 32))[0], True)
+    out["bottleneck_pooled_f64"], out["bottleneck_grad_names"], out["bottleneck_grad_norm_f64"] = y64, names, norms
+
+    def head():
+        return ref_network.ResNet18(ref_resnet.r2plus1d_18, fixconvs=False, nopretrained=False)
+    m = head()
+    weights = S.keyed_state_dict(m.state_dict(), seed=4, bn_jitter=True)
+    m.load_state_dict(weights)
+    m.eval()
+    with torch.no_grad():
+        out["resnet18_emb_eval_f32"] = m(x).numpy()
+    out["resnet18_keys"] = np.array(list(m.state_dict().keys()))
+    y64, names, norms = grads64(head, lambda mod, xx: mod(xx), False)
+    out["resnet18_emb_eval_f64"], out["resnet18_grad_names"], out["resnet18_grad_norm_f64"] = y64, names, norms
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     ref_network, _ = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
-    for name, fn in (("transforms", run_transforms), ("accuracy", run_accuracy)):
+    for name, fn in (("transforms", run_transforms), ("accuracy", run_accuracy), ("surface_extras", run_surface_extras)):
         if only and name not in only:
             continue
         t0 = time.time()
