@@ -293,10 +293,13 @@ def run_surface_extras():
 
     def grads64(build, run, mode_train):
         m = build().double()
+        if hasattr(m, "dropout"):
+            m.dropout = torch.nn.Identity()                  # (train-mode gradients without the RNG-dependent mask)
         m.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in weights.items()})
         m.train(mode_train)
         y = run(m, x.double())
-        (y * y).sum().backward()
+        # (an L2-normalised head makes sum(y^2) constant: project on the synthetic targets instead)
+        ((y * S.synthetic_targets(2)[1].double()).sum() if y.shape[1] == 300 else (y * y).sum()).backward()
         names = [k for k, p in m.named_parameters() if p.grad is not None]
         return y.detach().numpy(), np.array(names), np.array([dict(m.named_parameters())[k].grad.norm().item() for k in names])
 
@@ -324,8 +327,8 @@ def run_surface_extras():
     with torch.no_grad():
         out["resnet18_emb_eval_f32"] = m(x).numpy()
     out["resnet18_keys"] = np.array(list(m.state_dict().keys()))
-    y64, names, norms = grads64(head, lambda mod, xx: mod(xx), False)
-    out["resnet18_emb_eval_f64"], out["resnet18_grad_names"], out["resnet18_grad_norm_f64"] = y64, names, norms
+    y64, names, norms = grads64(head, lambda mod, xx: mod(xx), True)
+    out["resnet18_emb_train_nodrop_f64"], out["resnet18_grad_names"], out["resnet18_grad_norm_f64"] = y64, names, norms
     return out
 
 
