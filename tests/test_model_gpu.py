@@ -440,3 +440,40 @@ def test_odd_clip_sizes_forward_backward_match_the_oracle(n, t, h, w):
         worst = max(worst, ((a - b).norm() / (b.norm() + 1e-30)).item())
     # fp32 GPU vs fp32 CPU, different summation orders through ~40 layers of BatchNorm backward
     assert worst < 5e-2, f"worst per-parameter gradient rel-L2 {worst:.3e}"
+
+
+def test_weight_gradients_on_the_side_stream_are_the_same_bits(monkeypatch):
+    """ops: every convolution's wgrad runs on a side HIP stream (joined by an autograd-engine callback at the end of
+    backward).  Same kernels, same order per tensor: `.grad` read right after `loss.backward()` must equal, bit for bit,
+    the gradients of the single-stream run -- also when the optimizer step follows immediately."""
+    g, model, weights = build("r2plus1d_small")
+    x, z = case_inputs(g)
+    xd, zd = x.to(DEV), z.to(DEV)
+
+    def grads():
+        model.load_state_dict(weights)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        F.mse_loss(train.embed(model, xd), zd).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}     # (clone: main stream, after the join)
+
+    monkeypatch.setenv("ZSV_WGRAD_STREAM", "0")
+    ref = grads()
+    monkeypatch.setenv("ZSV_WGRAD_STREAM", "1")
+    for _ in range(2):
+        got = grads()
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+    # and through a full step: parameters after Adam agree too
+    def step():
+        model.load_state_dict(weights)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        train.train_step(model, opt, torch.nn.MSELoss(), xd, zd)
+        return {k: v.clone() for k, v in model.state_dict().items()}
+
+    a = step()
+    monkeypatch.setenv("ZSV_WGRAD_STREAM", "0")
+    b = step()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -165,6 +165,8 @@ class GradientSync:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
             self._side.wait_event(ready)
+            from . import ops
+            ops.join_wgrad_streams(self._side)        # weight gradients may come from their own side stream
             with torch.cuda.stream(self._side):
                 torch._foreach_copy_(b.views, grads)
                 if self.world > 1:

@@ -9,6 +9,8 @@ What each op replaces in the reference is cited next to it.
 """
 from __future__ import annotations
 
+import os
+
 from ctypes import byref, c_void_p
 from typing import Optional, Sequence, Tuple
 
@@ -55,6 +57,49 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes <= 0:
         return None
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ---- weight gradients on a side stream --------------------------------------------------------------
+# The weight gradient of a convolution is needed only by the optimizer step (or the data-parallel bucket it belongs to),
+# while the input gradient is on the critical path of backward.  Every wgrad launch therefore goes to a side HIP stream
+# (ZSV_WGRAD_STREAM=0 keeps it on the backward stream): the matrix-bound wgrad kernels then share the chip with the HBM-bound
+# BatchNorm / pooling passes of the layers below instead of queueing in front of them (step 50.1 -> 47.7 ms on one device,
+# profiles/r02_wgrad_side_stream_ab.txt; gradients are bit-identical, the kernels are the same).  The autograd engine runs a callback at the end of the backward pass that makes
+# the calling stream wait for the side stream, so `.grad` is safe to read right after `loss.backward()`.
+_WGRAD_SIDE = {}
+_WGRAD_JOIN_QUEUED = set()
+
+
+def wgrad_side_stream(device):
+    """The side stream for weight gradients on ``device`` (None with ZSV_WGRAD_STREAM=0)."""
+    if os.environ.get("ZSV_WGRAD_STREAM", "1") in ("", "0"):
+        return None
+    key = torch.device(device).index
+    st = _WGRAD_SIDE.get(key)
+    if st is None:
+        st = _WGRAD_SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_streams(stream=None):
+    """Make ``stream`` (default: the current one) wait for every weight gradient launched so far."""
+    for key, st in _WGRAD_SIDE.items():
+        with torch.cuda.device(key):
+            (stream or torch.cuda.current_stream()).wait_stream(st)
+
+
+def _queue_wgrad_join(device):
+    key = torch.device(device).index
+    if key in _WGRAD_JOIN_QUEUED:
+        return
+    _WGRAD_JOIN_QUEUED.add(key)
+    main = torch.cuda.current_stream(device)
+
+    def _join():
+        _WGRAD_JOIN_QUEUED.discard(key)
+        main.wait_stream(_WGRAD_SIDE[key])
+
+    torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 class KernelTimer:
@@ -185,11 +230,27 @@ class _Conv3d(Function):
                 _lib.check(lib.zsv_conv3d_dgrad_add(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
                                                     _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
             if ctx.needs_input_grad[1]:
-                dw = torch.empty_like(weight)
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
-                ws = _workspace(nbytes, dy.device)
-                _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
-                                                _stream()), "zsv_conv3d_wgrad")
+                side = wgrad_side_stream(dy.device)
+                if side is None:
+                    dw = torch.empty_like(weight)
+                    ws = _workspace(nbytes, dy.device)
+                    _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
+                                                    _stream()), "zsv_conv3d_wgrad")
+                else:
+                    main = torch.cuda.current_stream()
+                    ready = torch.cuda.Event()
+                    ready.record(main)                         # dy (and x) are complete on the backward stream here
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        dw = torch.empty_like(weight)
+                        ws = _workspace(nbytes, dy.device)
+                        _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
+                                                        c_void_p(side.cuda_stream)), "zsv_conv3d_wgrad")
+                    x.record_stream(side)                      # the side stream reads memory the backward stream owns
+                    dy.record_stream(side)
+                    dw.record_stream(main)                     # ... and the optimizer reads dw on the backward stream
+                    _queue_wgrad_join(dy.device)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = channel_sum(dy)
         return dx, dw, db, None, None, None, None, None
