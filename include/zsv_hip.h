@@ -94,6 +94,29 @@ int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, const float* w
 size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- convolution fed by a BatchNorm + ReLU that is never written out ------------------------------ */
+/* Conv2Plus1D runs `Conv3d(1x3x3) -> BatchNorm3d -> ReLU -> Conv3d(3x1x1)` (resnet.py:40-52).  Instead of one HBM pass
+ * that normalises the 636 MB mid tensor and a second that reads it back, the temporal convolution (forward and weight
+ * gradient) reads the RAW spatial output x and applies relu(x * scale[c] + shift[c]) on its way into the MFMA -- the same
+ * fmaf / max as the BatchNorm apply pass: results are bit-identical to the unfused sequence.
+ *   zsv_bn_fwd_train_coeffs : training-mode BatchNorm up to, but without, the normalise pass: batch statistics (from the
+ *       producing convolution's epilogue partials when given), save_mean / save_invstd, running statistics, and
+ *       coef = [2][coef_pitch] (scale row, shift row; coef_pitch >= C, a multiple of 16, tail zeroed; 16-byte aligned).
+ *   zsv_conv3d_pre_supported: 1 when both zsv_conv3d_fwd_pre and zsv_conv3d_wgrad_pre can run this geometry.
+ *   zsv_conv3d_fwd_pre / zsv_conv3d_wgrad_pre: zsv_conv3d_fwd_stats / zsv_conv3d_wgrad with x read through the affine + ReLU
+ *       (same workspace sizes as their plain forms).  The input gradient is zsv_conv3d_dgrad as usual (it is the gradient
+ *       w.r.t. the virtual activation), followed by zsv_bn_bwd(relu_mode = 2), which recomputes the ReLU mask from x. */
+int zsv_bn_fwd_train_coeffs(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma, const float* beta,
+                            float* save_mean, float* save_invstd, float* running_mean, float* running_var, float momentum,
+                            float eps, const float* conv_partials, int32_t stat_tiles, float* coef, int32_t coef_pitch,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int32_t zsv_conv3d_pre_supported(const zsv_conv_desc* d);
+int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch, const float* w,
+                       float* y, float* bn_partials, int32_t stat_tiles, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int zsv_conv3d_wgrad_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
+                         const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream);
 /* db[c] = sum over (n, s) of dy  (bias gradient of C3D's convs, network.py:102-117,
  * and of nn.Linear when S == 1). */
 size_t zsv_channel_sum_workspace_bytes(int32_t N, int32_t C, int32_t S);

@@ -779,3 +779,59 @@ def test_conv3d_wgrad_temporal_ring_path(case, monkeypatch):
     c = run()
     close(c, ref, what=f"{name} wgrad (frame ring, 7 slices)")
     assert not torch.equal(a, c), "the slice-count knob of the ring kernel had no effect: is the kernel in use?"
+
+
+@pytest.mark.parametrize("n,cin,cout,thw", [(2, 144, 64, (8, 32, 32)), (3, 230, 128, (4, 32, 48)), (2, 130, 56, (16, 16, 64))],
+                         ids=["t1_like", "ragged_230_to_128", "padded_rows_and_columns"])
+def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, monkeypatch):
+    """BatchNorm3d -> ReLU -> Conv3d(3x1x1) (Conv2Plus1D's mid tensor, resnet.py:46-52) with the normalise pass folded into
+    the convolution's forward and weight-gradient kernels: bit-identical to the unfused sequence (outputs, every gradient,
+    running statistics), and equal to the fp64 reference."""
+    from zeroshotvideoclassification_amd import layers
+    t, h, w = thw
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, t, h, w, generator=g) * 1.5 + 0.3
+    wt = torch.randn(cout, cin, 3, 1, 1, generator=g) / np.sqrt(cin * 3)
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    assert ops.conv_pre_supported(x.shape, wt.shape, 1, (1, 0, 0))
+
+    def run(fused):
+        bn = layers.BatchNorm3d(cin).to(DEV).train()
+        bn.weight.data.copy_(gamma)
+        bn.bias.data.copy_(beta)
+        conv = layers.Conv3d(cin, cout, kernel_size=(3, 1, 1), padding=(1, 0, 0), bias=False).to(DEV)
+        conv.weight.data.copy_(wt)
+        xg = x.to(DEV).requires_grad_()
+        mask = None
+        if fused:
+            handle, coef = bn.deferred(xg)
+            y, stats = conv.forward_pre(handle, coef, want_stats=True)
+        else:
+            act = bn(xg, relu=True)
+            mask = (act.detach() > 0).cpu()
+            y, stats = conv(act, want_stats=True)
+        y.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        return dict(y=y.detach(), stats=stats, dx=xg.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad, dw=conv.weight.grad,
+                    rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nbt=bn.num_batches_tracked.clone()), mask
+
+    (a, _), (b, mask) = run(True), run(False)
+    for k in a:
+        assert (a[k] is None) == (b[k] is None), k
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), f"fused vs unfused differ in {k}"
+    xr = x.double().requires_grad_()
+    gr, br, wr = gamma.double().requires_grad_(), beta.double().requires_grad_(), wt.double().requires_grad_()
+    # (the reference uses the device's own ReLU mask: a pre-activation within rounding of 0 may differ in sign)
+    yr = F.conv3d(F.batch_norm(xr, None, None, gr, br, training=True) * mask.double(), wr, padding=(1, 0, 0))
+    yr.backward(dy.double())
+    close(a["y"], yr, what="folded bn+relu+conv forward")
+    close(a["dx"], xr.grad, rtol=1e-4, what="folded dx")
+    close(a["dw"], wr.grad, rtol=5e-5, what="folded dw")
+    close(a["dgamma"], gr.grad, rtol=1e-4, what="folded dgamma")
+    close(a["dbeta"], br.grad, rtol=1e-4, what="folded dbeta")
+    monkeypatch.setenv("ZSV_NO_BN_FUSION", "1")
+    assert not ops.conv_pre_supported(x.shape, wt.shape, 1, (1, 0, 0))
+    # geometries without a fused path say so (strided, spatial taps, too few voxels) and the chain falls back
+    assert not ops.conv_pre_supported((2, 64, 8, 32, 32), (144, 64, 1, 3, 3), 1, (0, 1, 1))

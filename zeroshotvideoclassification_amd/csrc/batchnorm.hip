@@ -443,6 +443,39 @@ extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int3
     return launch_apply(x, residual, y, N, C, S, w.scale, w.shift, fuse_relu, stream);
 }
 
+// Training-mode BatchNorm WITHOUT the normalise pass: statistics (own pass or the producing convolution's epilogue partials),
+// save_mean / save_invstd, running statistics, and the per-channel affine y = x * scale + shift written to `coef`
+// ([2][coef_pitch]: scale row, shift row; entries C .. coef_pitch-1 are set to 0).  The consumer applies it (+ ReLU) while
+// it reads x: zsv_conv3d_fwd_pre / zsv_conv3d_wgrad_pre.  The backward is zsv_bn_bwd with relu_mode 2 (mask recomputed from x).
+extern "C" int zsv_bn_fwd_train_coeffs(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma, const float* beta,
+                                       float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                                       float momentum, float eps, const float* conv_partials, int32_t stat_tiles, float* coef,
+                                       int32_t coef_pitch, void* workspace, size_t workspace_bytes, void* stream_) {
+    int st = check_ncs(N, C, S);
+    if (st) return st;
+    if (!x || !save_mean || !save_invstd || !workspace || !coef) return ZSV_E_NULL;
+    if (coef_pitch < C) return ZSV_E_BAD_SHAPE;
+    if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    int slices = bn_slices(N, C, S);
+    BnWs w = bn_ws(workspace, C, slices);
+    const float* pivot_src = x;
+    if (conv_partials && stat_tiles > 0) {
+        pivot_src = nullptr;
+        hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
+                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, w.part);
+        slices = 1;
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+    }
+    if ((st = launch_status())) return st;
+    if (coef_pitch > C && hipMemsetAsync(coef, 0, (size_t)2 * coef_pitch * sizeof(float), stream) != hipSuccess) return ZSV_E_LAUNCH;
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
+                       slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
+                       momentum, eps, coef, coef + coef_pitch);
+    return launch_status();
+}
+
 extern "C" int zsv_bn_fwd_eval(const float* x, int32_t N, int32_t C, int32_t S, const float* gamma, const float* beta,
                                const float* running_mean, const float* running_var, const float* residual,
                                int fuse_relu, float eps, float* y, void* workspace, size_t workspace_bytes,

@@ -170,6 +170,47 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
     return igemm_generic(p, avec, w, x, bias, y, (hipStream_t)stream);
 }
 
+// ---- convolution of a BatchNorm + ReLU output that is never materialised -----------------------------------------
+// (Conv2Plus1D's `BatchNorm3d(mid) -> ReLU -> temporal conv`, resnet.py:46-52): both the forward (direct kernel, PRE form)
+// and the weight gradient (frame-ring kernel, PRE form) must be able to apply the affine + ReLU while they read x.
+extern "C" int32_t zsv_conv3d_pre_supported(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK || wino_fwd_applicable(d) || getenv("ZSV_NO_BN_FUSION")) return 0;
+    IgemmParams p;
+    fwd_params(p, d, 0);
+    return (igemm_tap_applicable(p) && wgrad_tring_applicable(d, nullptr, nullptr)) ? 1 : 0;
+}
+
+extern "C" int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
+                                  const float* w, float* y, float* bn_partials, int32_t stat_tiles, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    int st = conv_check(d);
+    if (st) return st;
+    if (!x || !w || !y || !pre_coef) return ZSV_E_NULL;
+    if (!zsv_conv3d_pre_supported(d) || coef_pitch < d->Cin || coef_pitch % 16 != 0 ||
+        (reinterpret_cast<uintptr_t>(pre_coef) & 15) != 0)
+        return ZSV_E_UNSUPPORTED;
+    IgemmParams p;
+    fwd_params(p, d, 0);
+    p.pre_coef = pre_coef;
+    p.pre_pitch = coef_pitch;
+    if (bn_partials) {
+        if (stat_tiles <= 0 || stat_tiles != igemm_tap_stat_tiles(p, y)) return ZSV_E_UNSUPPORTED;
+        p.stat_sum = bn_partials;
+        p.stat_sq = bn_partials + (size_t)d->Cout * stat_tiles;
+        p.tiles_n = stat_tiles;
+    }
+    if (workspace_bytes < zsv_conv3d_fwd_workspace_bytes(d) || !workspace) return ZSV_E_WORKSPACE;
+    const int ks = igemm_tap_ksplit(p);
+    const size_t wbytes = align256(igemm_tap_workspace_bytes(p));
+    const long out_elems = (long)d->N * d->Cout * d->To * d->Ho * d->Wo;
+    float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
+    p.ksplit = ks;
+    p.slab_elems = (int)out_elems;
+    st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, nullptr, y, workspace, wbytes, slabs, (hipStream_t)stream);
+    if (st || ks <= 1) return st;
+    return splitk_reduce(slabs, ks, out_elems, d->Cout, p.oS, nullptr, 0, y, (hipStream_t)stream);
+}
+
 // one split factor for every residue class of a dgrad call (they share the slabs)
 static int dgrad_plan(const zsv_conv_desc* d, size_t& wbytes) {
     IgemmParams p;

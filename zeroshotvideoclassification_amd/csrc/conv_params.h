@@ -34,6 +34,8 @@ struct IgemmParams {
     float* stat_sum;    // != nullptr (lds_epilogue only): per (channel, column tile) partial sum and sum of
     float* stat_sq;     //   squares of the produced values, [M][tiles_n] each -- BatchNorm statistics for free
     int tiles_n;
+    const float* pre_coef;  // != nullptr: the gathered tensor is read as relu(g * scale[c] + shift[c]) -- a BatchNorm + ReLU that
+    int pre_pitch;          //   was never materialised; [2][pre_pitch] floats (scale row, shift row), zero beyond gC (conv_tap.hip PRE)
     const float* acc_src;   // != nullptr (no split-K): C = act(result + acc_src + bias), acc_src laid out like C -- the
                             //   gradient of an identity shortcut in a dgrad, or `out += residual` of an inference forward
                             //   (resnet.py:110), added in the epilogue
@@ -208,6 +210,8 @@ int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream);
 // ordered reduction; writes dw
 bool wgrad_tring_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
 size_t wgrad_tring_workspace_bytes(const zsv_conv_desc* d);
+int wgrad_tring_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* dy, float* dw,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream);
 int wgrad_tring(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                 hipStream_t stream);
 // Winograd-form weight gradient of the 1x3x3 / 3x3x3 stride-1 "same" convolutions (conv_wgrad_wino.hip): slabs, mask

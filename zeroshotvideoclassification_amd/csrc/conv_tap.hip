@@ -75,7 +75,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // NBLK_CT / TAPS_CT: compile-time channel-block and tap counts (0 = run time).  The one
 // specialisation (4, 9) is the network's dominant layer, Conv3d(64, 144, (1,3,3)) forward: its
 // chunk walk is fully constant-folded, and it gets a kernel symbol of its own in profiles.
-template <int TM, int TN, int WGM, int WGN, int FK, int NBLK_CT = 0, int TAPS_CT = 0>     // FK = MFMA k-steps per fragment burst
+// PRE: the gathered tensor is the INPUT of a BatchNorm + ReLU that was never materialised (zsv_bn_fwd_train_coeffs): a B
+// fragment value becomes relu(g * scale[c] + shift[c]) on its way into the MFMA -- the same fmaf and max as the BatchNorm
+// apply pass, so results are bit-identical to reading the materialised activation.  Per chunk wave 0 DMAs the 16 channels'
+// scale / shift next to the operands; zero padding must stay zero, so every lane keeps the tap-validity word of its TN
+// fragment columns (exchanged through LDS once) and zeroes the padded taps' values instead.
+template <int TM, int TN, int WGM, int WGN, int FK, int NBLK_CT = 0, int TAPS_CT = 0, bool PRE = false>     // FK = MFMA k-steps per fragment burst
 __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmParams prm, const float* __restrict__ Wp,
                                                            const float* __restrict__ G, const float* __restrict__ bias,
                                                            float* __restrict__ C, int tiles_m, int Mp, int nblk) {
@@ -97,6 +102,8 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     // one LDS pool: As[2] | Bs[2] during the main loop, re-used by the transposing epilogue
     __shared__ __attribute__((aligned(16))) float pool[2 * BK * (LDA + LDB)];
     __shared__ int tapoff[32];
+    __shared__ __attribute__((aligned(16))) float pre_lds[PRE ? 2 * 256 : 4];   // per stage: 1 KiB DMA target, 32 floats used
+    __shared__ unsigned vmask_lds[PRE ? BN : 1];
     float (*As)[BK * LDA] = reinterpret_cast<float (*)[BK * LDA]>(pool);
     float (*Bs)[BK * LDB] = reinterpret_cast<float (*)[BK * LDB]>(pool + 2 * BK * LDA);
 
@@ -150,6 +157,10 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
         }
     }
 
+    if constexpr (PRE) {
+        if (brow0 == 0) vmask_lds[bcol0 + lane] = vmask;        // (the waves of the first k-row cover the BN columns once)
+    }
+
     // ---- weight panel: per pass, the source of this lane's float4 slot of the padded image --
     const float* a_src[APASS];
 #pragma unroll
@@ -160,6 +171,8 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     }
     const size_t a_chunk_stride = (size_t)BK * Mp;
     const int ch_bytes = 4 * prm.gS;
+    const __amdgpu_buffer_rsrc_t pre_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? prm.pre_coef : G), 0, PRE ? 8u * (unsigned)prm.pre_pitch : 0u, 0x00020000);
 
     const int taps_ = TAPS_CT ? TAPS_CT : prm.taps;
     const int nblk_ = NBLK_CT ? NBLK_CT : nblk;
@@ -194,6 +207,12 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
                 __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)(c_begin + chunk) * a_chunk_stride,
                                                  (lds_ptr_t)(&As[buf][256 * (wave + 4 * j)]), 16, 0, 0);
         }
+        if constexpr (PRE) {
+            if (wave == 0) {        // lanes 0..3: scale[ci0 .. ci0+15], lanes 4..7: shift[...]; the others read out of range (zeros)
+                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(&pre_lds[buf * 256]), 16, (int)off, 0, 0, 0);
+            }
+        }
         if (++ld_tap == taps_) { ld_tap = 0; ++ld_cb; }
     };
 
@@ -210,11 +229,29 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     const int frag_row = lane >> 4;
     const int frag_col = lane & 15;
     constexpr int NS = (BK / 4) / FK;     // fragment bursts per chunk
+    unsigned vmf[PRE ? TN : 1];           // PRE: tap-validity words of this lane's fragment columns
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) vmf[j] = vmask_lds[wn0 + 16 * j + frag_col];      // (published before the barriers above)
+    }
+    int cur_tap = c_begin - (c_begin / taps_) * taps_;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
         if (ch + 1 < nchunks) issue_chunk(ch + 1, cur ^ 1);
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
+        float psc[PRE ? BK / 4 : 1], psh[PRE ? BK / 4 : 1];
+        bool pok[PRE ? TN : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int q = 0; q < BK / 4; ++q) {                 // this lane's k rows: 4 q + frag_row
+                psc[q] = pre_lds[cur * 256 + 4 * q + frag_row];
+                psh[q] = pre_lds[cur * 256 + 16 + 4 * q + frag_row];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pok[j] = (vmf[j] >> cur_tap) & 1u;
+            if (++cur_tap == taps_) cur_tap = 0;
+        }
         float a[2][FK][TM], b[2][FK][TN];
         auto fetch = [&](int s_, int slot) {
 #pragma unroll
@@ -229,6 +266,15 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
             if (s_ + 1 < NS) fetch(s_ + 1, (s_ + 1) & 1);
+            if constexpr (PRE) {
+#pragma unroll
+                for (int kk = 0; kk < FK; ++kk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float t = fmaxf(__fmaf_rn(b[s_ & 1][kk][j], psc[FK * s_ + kk], psh[FK * s_ + kk]), 0.f);
+                        b[s_ & 1][kk][j] = pok[j] ? t : 0.f;
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);          // the MFMA burst outranks the other waves' staging / address work (+0.5 %)
 #pragma unroll
@@ -363,11 +409,16 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
     const long blocks = (long)tiles_m * (((long)prm.P + BN - 1) / BN) * (prm.ksplit > 1 ? prm.ksplit : 1);
     if (blocks <= 0 || blocks > 0x7fffffffL) return ZSV_E_TOO_LARGE;
     if constexpr (TM == 9 && TN == 2) {
-        if (prm.dir == 1 && prm.taps == 9 && nblk == 4 && prm.ksplit <= 1) {
+        if (prm.dir == 1 && prm.taps == 9 && nblk == 4 && prm.ksplit <= 1 && prm.pre_coef == nullptr) {
             hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1, 4, 9>), dim3((unsigned)blocks), dim3(256), 0,
                                stream, prm, Wp, G, bias, C, tiles_m, Mp, nblk);
             return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
         }
+    }
+    if (prm.pre_coef != nullptr) {
+        hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1, 0, 0, true>), dim3((unsigned)blocks), dim3(256), 0, stream, prm,
+                           Wp, G, bias, C, tiles_m, Mp, nblk);
+        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
     }
     hipLaunchKernelGGL((conv_tap_dma_kernel<TM, TN, WGM, WGN, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, prm, Wp, G,
                        bias, C, tiles_m, Mp, nblk);

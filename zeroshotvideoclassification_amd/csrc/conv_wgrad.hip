@@ -470,6 +470,16 @@ extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
     return need;
 }
 
+extern "C" int zsv_conv3d_wgrad_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
+                                    const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream_) {
+    int st = conv_check(d);
+    if (st) return st;
+    if (!x || !dy || !dw || !pre_coef) return ZSV_E_NULL;
+    if (!zsv_conv3d_pre_supported(d) || coef_pitch < d->Cin || !wgrad_tring_applicable(d, x, dy)) return ZSV_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < zsv_conv3d_wgrad_workspace_bytes(d)) return ZSV_E_WORKSPACE;
+    return wgrad_tring_pre(d, x, pre_coef, coef_pitch, dy, dw, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
 extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
     int st = conv_check(d);

@@ -31,11 +31,16 @@ struct WgradTringParams {
     int chunks_total, chunks_per_slice;
     unsigned x_bytes, dy_bytes;
     int tiles_m, tiles_mn;
+    const float* pre_coef;            // PRE: X is read as relu(X * scale[ci] + shift[ci]) -- [2][pre_pitch] (scale row, shift row)
+    int pre_pitch;
 };
 
 __device__ __forceinline__ int tring_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-template <int TM>
+// PRE: the convolution's input is the output of BatchNorm + ReLU that was never materialised (zsv_bn_fwd_train_coeffs): a
+// lane's X values all belong to its own row (input channel), so the affine + ReLU is two VALU ops per value with two
+// registers per row block -- bit-identical to reading the materialised activation (same fmaf, same max).
+template <int TM, bool PRE = false>
 __global__ __launch_bounds__(256, 3) void conv_wgrad_tring_kernel(WgradTringParams prm, const float* __restrict__ X,
                                                                   const float* __restrict__ DY, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -92,6 +97,15 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tring_kernel(WgradTringPara
 
     const int g = lane >> 4, r16 = lane & 15;
     const int frag = r16 * 64 + ((g ^ tring_swz(r16)) << 4);
+    float pre_sc[PRE ? TM : 1], pre_sh[PRE ? TM : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ci = m0 + 16 * i + r16;
+            pre_sc[i] = ci < prm.Cin ? prm.pre_coef[ci] : 0.f;
+            pre_sh[i] = ci < prm.Cin ? prm.pre_coef[prm.pre_pitch + ci] : 0.f;
+        }
+    }
     int kt_of[3], cob_of[3];                                // tap and 16-channel block of this wave's three column blocks
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -143,6 +157,10 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_tring_kernel(WgradTringPara
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (i + 1 < TM) af[(i + 1) & 1] = *reinterpret_cast<const f32x4*>(as + (i + 1) * 1024);
+            if constexpr (PRE) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) af[i & 1][s] = fmaxf(__fmaf_rn(af[i & 1][s], pre_sc[i], pre_sh[i]), 0.f);
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -263,20 +281,26 @@ size_t wgrad_tring_workspace_bytes(const zsv_conv_desc* d) {
     return (size_t)pl.slices * d->Cin * 3 * d->Cout * sizeof(float);
 }
 
-template <int TM>
+template <int TM, bool PRE>
 static int wgrad_tring_launch(const WgradTringParams& p, int slices, hipStream_t stream, const float* x, const float* dy,
                               float* out) {
     constexpr int LDS_BYTES = 2 * TM * 1024 + 4 * 4096;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_tring_kernel<TM>,
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_tring_kernel<TM, PRE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    hipLaunchKernelGGL(conv_wgrad_tring_kernel<TM>, dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
+    hipLaunchKernelGGL((conv_wgrad_tring_kernel<TM, PRE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, out);
     return launch_status();
 }
 
 int wgrad_tring(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
                 hipStream_t stream) {
+    return wgrad_tring_pre(d, x, nullptr, 0, dy, dw, workspace, workspace_bytes, stream);
+}
+
+// pre_coef != nullptr: x is the INPUT of a BatchNorm + ReLU whose output is the convolution's input (see the kernel's PRE)
+int wgrad_tring_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* dy, float* dw,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream) {
     const WgradTringPlan pl = wgrad_tring_plan(d);
     if (!workspace || workspace_bytes < wgrad_tring_workspace_bytes(d)) return ZSV_E_WORKSPACE;
     WgradTringParams p;
@@ -287,9 +311,13 @@ int wgrad_tring(const zsv_conv_desc* d, const float* x, const float* dy, float* 
     p.x_bytes = 4u * (unsigned)((long)d->N * d->Cin * p.S);
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
+    p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
     float* slabs = (float*)workspace;
-    const int st = pl.tm == 9 ? wgrad_tring_launch<9>(p, pl.slices, stream, x, dy, slabs)
-                              : wgrad_tring_launch<8>(p, pl.slices, stream, x, dy, slabs);
+    int st;
+    if (pre_coef) st = pl.tm == 9 ? wgrad_tring_launch<9, true>(p, pl.slices, stream, x, dy, slabs)
+                                  : wgrad_tring_launch<8, true>(p, pl.slices, stream, x, dy, slabs);
+    else st = pl.tm == 9 ? wgrad_tring_launch<9, false>(p, pl.slices, stream, x, dy, slabs)
+                         : wgrad_tring_launch<8, false>(p, pl.slices, stream, x, dy, slabs);
     if (st) return st;
     const long n = (long)d->Cin * 3 * d->Cout;
     long blocks = (n + 31) / 32;

@@ -27,12 +27,29 @@ class Conv3d(nn.Conv3d):
         the kernel epilogue (None when the geometry does not provide them)."""
         return ops.conv3d(x, self.weight, self.bias, self.stride, self.padding, relu=relu, want_stats=want_stats)
 
+    def pre_supported(self, x_shape) -> bool:
+        """Can this convolution take a training-mode ``BatchNorm3d -> ReLU`` in front of it inside its own kernels?"""
+        return self.bias is None and ops.conv_pre_supported(x_shape, self.weight.shape, self.stride, self.padding)
+
+    def forward_pre(self, x, coef, want_stats: bool = False):
+        """``self(relu(x * scale + shift))`` with ``coef`` from ``BatchNorm3d.deferred``: the normalised tensor is never
+        written (resnet.py:46-52, the mid tensor of ``Conv2Plus1D``)."""
+        return ops.conv3d_pre(x, coef, self.weight, self.stride, self.padding, want_stats=want_stats)
+
 
 class BatchNorm3d(nn.BatchNorm3d):
-    def forward(self, x, residual=None, relu: bool = False, stats=None, skip_link=None):
+    def forward(self, x, residual=None, relu: bool = False, stats=None, skip_link=None, defer: bool = False):
+        """``defer=True`` (training mode, followed by ReLU and a convolution that ``pre_supported`` it): statistics, running
+        statistics and the affine coefficients WITHOUT the normalise pass -- returns ``(x_handle, coef)`` for
+        ``Conv3d.forward_pre``."""
         if x.dim() != 5:
             raise ValueError(f"expected 5D input (got {x.dim()}D input)")
+        if defer:
+            return ops.bn_module_deferred(x, self, stats=stats)
         return ops.bn_module_act(x, self, residual=residual, relu=relu, stats=stats, skip_link=skip_link)
+
+    def deferred(self, x, stats=None):
+        return self(x, stats=stats, defer=True)
 
 
 class ReLU(nn.ReLU):

@@ -88,6 +88,25 @@ def join_wgrad_streams(stream=None):
             (stream or torch.cuda.current_stream()).wait_stream(st)
 
 
+def _on_wgrad_stream(launch, inputs):
+    """Run ``launch(stream_handle) -> dw`` on the weight-gradient side stream (or the current stream when it is disabled)."""
+    dev = inputs[-1].device
+    side = wgrad_side_stream(dev)
+    if side is None:
+        return launch(_stream())
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)                                 # the operands are complete on the backward stream here
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        dw = launch(c_void_p(side.cuda_stream))        # (dw and the workspace come from the side stream's pool)
+    for t in inputs:
+        t.record_stream(side)                          # the side stream reads memory the backward stream owns
+    dw.record_stream(main)                             # ... and the optimizer reads dw on the backward stream
+    _queue_wgrad_join(dev)
+    return dw
+
+
 def _queue_wgrad_join(device):
     key = torch.device(device).index
     if key in _WGRAD_JOIN_QUEUED:
@@ -231,26 +250,15 @@ class _Conv3d(Function):
                                                     _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
             if ctx.needs_input_grad[1]:
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
-                side = wgrad_side_stream(dy.device)
-                if side is None:
-                    dw = torch.empty_like(weight)
+
+                def launch(stream):
+                    out = torch.empty_like(weight)
                     ws = _workspace(nbytes, dy.device)
-                    _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
-                                                    _stream()), "zsv_conv3d_wgrad")
-                else:
-                    main = torch.cuda.current_stream()
-                    ready = torch.cuda.Event()
-                    ready.record(main)                         # dy (and x) are complete on the backward stream here
-                    side.wait_event(ready)
-                    with torch.cuda.stream(side):
-                        dw = torch.empty_like(weight)
-                        ws = _workspace(nbytes, dy.device)
-                        _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), nbytes,
-                                                        c_void_p(side.cuda_stream)), "zsv_conv3d_wgrad")
-                    x.record_stream(side)                      # the side stream reads memory the backward stream owns
-                    dy.record_stream(side)
-                    dw.record_stream(main)                     # ... and the optimizer reads dw on the backward stream
-                    _queue_wgrad_join(dy.device)
+                    _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(), _ptr(ws), nbytes,
+                                                    stream), "zsv_conv3d_wgrad")
+                    return out
+
+                dw = _on_wgrad_stream(launch, (x, dy))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = channel_sum(dy)
         return dx, dw, db, None, None, None, None, None
@@ -376,6 +384,151 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, tra
     (``conv3d(..., want_stats=True)``); the kernel then skips its own pass over ``x``."""
     return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, residual, bool(training), float(momentum),
                                float(eps), bool(relu), stats if training else None, skip_link)
+
+
+# ------------------------------------------------------------------------------------------
+# BatchNorm + ReLU folded into the convolution that consumes it (Conv2Plus1D's mid tensor, resnet.py:46-52)
+class _BatchNormDeferred(Function):
+    """Training-mode ``BatchNorm3d`` up to, but without, the normalise pass: returns its input (as the handle the
+    consuming convolution differentiates against) and ``coef`` = per-channel (scale, shift).  The consumer
+    (``conv3d_pre``) reads ``relu(x * scale + shift)`` on the fly; its input gradient is the gradient w.r.t. that virtual
+    activation, which is exactly what this backward expects (``zsv_bn_bwd`` with the ReLU mask recomputed from x)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, stats):
+        _require(x, gamma, beta, running_mean, running_var, stats)
+        if not x.is_contiguous():
+            raise RuntimeError("deferred BatchNorm needs a contiguous input")
+        n, c = int(x.shape[0]), int(x.shape[1])
+        s = x.numel() // (n * c)
+        lib = _lib.load()
+        pitch = (c + 15) // 16 * 16
+        coef = torch.empty((2, pitch), dtype=torch.float32, device=x.device)
+        save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        tiles = 0
+        if stats is not None:
+            if stats.dim() != 3 or stats.shape[0] != 2 or stats.shape[1] != c or not stats.is_contiguous():
+                raise RuntimeError("conv statistics do not match this BatchNorm")
+            tiles = int(stats.shape[2])
+        nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
+        ws = _workspace(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zsv_bn_fwd_train_coeffs(x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                                   save_invstd.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                                   float(momentum), float(eps), _ptr(stats), tiles, coef.data_ptr(), pitch,
+                                                   _ptr(ws), nbytes, _stream()), "zsv_bn_fwd_train_coeffs")
+        if running_mean is not None:
+            _lib.note_raw_write()
+        ctx.dims = (n, c, s)
+        ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
+        ctx.mark_non_differentiable(coef)
+        return x.view_as(x), coef
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _dcoef=None):
+        x, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
+        n, c, s = ctx.dims
+        lib = _lib.load()
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+        nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
+        ws = _workspace(nbytes, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.zsv_bn_bwd(g.data_ptr(), x.data_ptr(), None, n, c, s, _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 2, dx.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(),
+                                      _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
+        return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None)
+
+
+class _Conv3dPre(Function):
+    """``conv3d(relu(x * scale + shift), w)`` with the affine + ReLU applied inside the kernels (forward: the direct kernel's
+    PRE form; weight gradient: the frame-ring kernel's PRE form)."""
+
+    @staticmethod
+    def forward(ctx, x, coef, weight, stride, padding, want_stats):
+        _require(x, coef, weight)
+        weight = weight.contiguous()
+        d = conv_desc(x.shape, weight.shape, stride, padding)
+        lib = _lib.load()
+        if not lib.zsv_conv3d_pre_supported(byref(d)):
+            raise RuntimeError("conv3d_pre: this geometry has no fused BatchNorm path (check conv_pre_supported first)")
+        y = torch.empty((d.N, d.Cout, d.To, d.Ho, d.Wo), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            nbytes = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+            ws = _workspace(nbytes, x.device)
+            tiles, stats = 0, None
+            if want_stats:
+                tiles = lib.zsv_conv3d_fwd_stat_tiles(byref(d), y.data_ptr())
+                if tiles > 0:
+                    stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
+            _lib.check(lib.zsv_conv3d_fwd_pre(byref(d), x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), weight.data_ptr(),
+                                              y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd_pre")
+        ctx.desc = d
+        ctx.save_for_backward(x, coef, weight)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dstats=None):
+        x, coef, weight = ctx.saved_tensors
+        d = ctx.desc
+        lib = _lib.load()
+        if dy is None:
+            return None, None, None, None, None, None
+        dy = dy.contiguous()
+        dx = dw = None
+        with torch.cuda.device(dy.device):
+            if ctx.needs_input_grad[0]:                     # gradient w.r.t. the virtual activation relu(bn(x))
+                dx = torch.empty_like(x)
+                nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
+                ws = _workspace(nbytes, dy.device)
+                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws), nbytes,
+                                                _stream()), "zsv_conv3d_dgrad")
+            if ctx.needs_input_grad[2]:
+                nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
+                pitch = int(coef.shape[1])
+
+                def launch(stream):
+                    out = torch.empty_like(weight)
+                    ws = _workspace(nbytes, dy.device)
+                    _lib.check(lib.zsv_conv3d_wgrad_pre(byref(d), x.data_ptr(), coef.data_ptr(), pitch, dy.data_ptr(),
+                                                        out.data_ptr(), _ptr(ws), nbytes, stream), "zsv_conv3d_wgrad_pre")
+                    return out
+
+                dw = _on_wgrad_stream(launch, (x, coef, dy))
+        return dx, None, dw, None, None, None
+
+
+def conv_pre_supported(x_shape, weight_shape, stride, padding) -> bool:
+    d = conv_desc(x_shape, weight_shape, stride, padding)
+    return bool(_lib.load().zsv_conv3d_pre_supported(byref(d)))
+
+
+def bn_module_deferred(x, bn: torch.nn.Module, stats=None):
+    """``bn`` in training mode without its normalise pass: ``(x_handle, coef)`` for ``conv3d_pre`` (running statistics
+    and ``num_batches_tracked`` are updated exactly as ``bn_module_act`` does)."""
+    if bn.momentum is None or not bn.training:
+        raise RuntimeError("deferred BatchNorm: training mode with a momentum only")
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormDeferred.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), stats)
+
+
+def conv3d_pre(x, coef, weight, stride=1, padding=0, want_stats=False):
+    y, stats = _Conv3dPre.apply(x, coef, weight, _triple(stride), _triple(padding), bool(want_stats))
+    return (y, stats) if want_stats else y
 
 
 _NBT_PENDING = None      # list of num_batches_tracked buffers to increment when the enclosing forward ends

@@ -50,6 +50,18 @@ def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
         nxt = mods[i + 1] if i + 1 < n else None
         if isinstance(m, BatchNorm3d):
             relu = isinstance(nxt, nn.ReLU)
+            after = mods[i + 2] if (relu and i + 2 < n) else None
+            if relu and m.training and m.momentum is not None and type(after) is Conv3d and x.is_contiguous() \
+                    and after.pre_supported(x.shape):
+                # BN -> ReLU -> conv (Conv2Plus1D's mid tensor, resnet.py:46-52): the convolution applies the affine +
+                # ReLU while it reads the raw tensor; the normalised tensor is never written or read back
+                handle, coef = m(x, stats=stats, defer=True)
+                after_next = mods[i + 3] if i + 3 < n else None
+                feeds = isinstance(after_next, BatchNorm3d) and after_next.training
+                x, stats = after.forward_pre(handle, coef, want_stats=True) if (feeds or (i + 3 == n and want_stats)) \
+                    else (after.forward_pre(handle, coef), None)
+                i += 3
+                continue
             x = m(x, relu=relu, stats=stats)
             stats = None
             i += 2 if relu else 1
