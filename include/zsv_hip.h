@@ -163,6 +163,10 @@ int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32_t N, int32
 int zsv_relu_fwd(const float* x, float* y, int64_t n, void* stream);
 /* dx = dy * (y > 0), y = saved output. */
 int zsv_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+/* dx = dy * (y > 0) AND db[c] = sum over (n, s) of that, in one pass (backward of C3D's fused `relu(conv(x) + bias)`,
+ * network.py:147-162); (N, C, S) tensors; workspace as zsv_channel_sum. */
+int zsv_relu_bwd_bias(const float* dy, const float* y, float* dx, int32_t N, int32_t C, int32_t S, float* db,
+                      void* workspace, size_t workspace_bytes, void* stream);
 /* out = relu(a + b): `out += residual; relu(out)` (resnet.py:110-111) when no BN is fused. */
 int zsv_add_relu_fwd(const float* a, const float* b, float* y, int64_t n, void* stream);
 

@@ -246,7 +246,9 @@ def test_relu_add_relu_meanpool():
 
 
 POOL_CASES = [((1, 2, 2), (0, 0, 0), (2, 3, 4, 8, 8)), ((2, 2, 2), (0, 0, 0), (1, 5, 4, 6, 6)),
-              ((2, 2, 2), (0, 1, 1), (2, 4, 2, 7, 7)), ((2, 2, 2), (0, 0, 0), (1, 2, 5, 9, 7))]
+              ((2, 2, 2), (0, 1, 1), (2, 4, 2, 7, 7)), ((2, 2, 2), (0, 0, 0), (1, 2, 5, 9, 7)),
+              ((2, 2, 2), (0, 1, 1), (2, 4, 2, 8, 8)), ((1, 2, 2), (0, 0, 0), (1, 3, 4, 12, 16)),      # W % 4 == 0: the quad backward
+              ((2, 2, 2), (0, 0, 0), (3, 5, 4, 10, 12))]
 
 
 @pytest.mark.parametrize("k,p,shape", POOL_CASES)

@@ -59,6 +59,7 @@ SIGNATURES = {
                            c_size_t, _P]),
     "zsv_relu_fwd": (c_int, [_P, _P, c_int64, _P]),
     "zsv_relu_bwd": (c_int, [_P, _P, _P, c_int64, _P]),
+    "zsv_relu_bwd_bias": (c_int, [_P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "zsv_add_relu_fwd": (c_int, [_P, _P, _P, c_int64, _P]),
     "zsv_meanpool_fwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_meanpool_bwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),

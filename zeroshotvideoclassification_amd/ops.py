@@ -237,7 +237,17 @@ class _Conv3d(Function):
         with torch.cuda.device(dy.device):
             if ctx.relu:
                 g = torch.empty_like(dy)
-                _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    # ReLU mask and bias gradient in one pass over dy (C3D: every convolution has both)
+                    n_, c_ = int(dy.shape[0]), int(dy.shape[1])
+                    s_ = dy.numel() // (n_ * c_)
+                    db = torch.empty(c_, dtype=torch.float32, device=dy.device)
+                    nb = lib.zsv_channel_sum_workspace_bytes(n_, c_, s_)
+                    wsb = _workspace(nb, dy.device)
+                    _lib.check(lib.zsv_relu_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), n_, c_, s_, db.data_ptr(),
+                                                     _ptr(wsb), nb, _stream()), "zsv_relu_bwd_bias")
+                else:
+                    _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
                 dy = g
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
@@ -259,7 +269,7 @@ class _Conv3d(Function):
                     return out
 
                 dw = _on_wgrad_stream(launch, (x, dy))
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = channel_sum(dy)
         return dx, dw, db, None, None, None, None, None
 
@@ -746,7 +756,17 @@ class _Linear(Function):
         with torch.cuda.device(dy.device):
             if ctx.relu:
                 g = torch.empty_like(dy)
-                _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
+                if ctx.has_bias and ctx.needs_input_grad[2]:
+                    # ReLU mask and bias gradient in one pass over dy (C3D: every convolution has both)
+                    n_, c_ = int(dy.shape[0]), int(dy.shape[1])
+                    s_ = dy.numel() // (n_ * c_)
+                    db = torch.empty(c_, dtype=torch.float32, device=dy.device)
+                    nb = lib.zsv_channel_sum_workspace_bytes(n_, c_, s_)
+                    wsb = _workspace(nb, dy.device)
+                    _lib.check(lib.zsv_relu_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), n_, c_, s_, db.data_ptr(),
+                                                     _ptr(wsb), nb, _stream()), "zsv_relu_bwd_bias")
+                else:
+                    _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
                 dy = g
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
@@ -760,7 +780,7 @@ class _Linear(Function):
                 ws = _workspace(nbytes, dy.device)
                 _lib.check(lib.zsv_linear_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), rows, fin, fout, _ptr(ws),
                                                 nbytes, _stream()), "zsv_linear_wgrad")
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = channel_sum(dy)
         return dx, dw, db, None
 
