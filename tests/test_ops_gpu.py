@@ -837,3 +837,80 @@ def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, 
     assert not ops.conv_pre_supported(x.shape, wt.shape, 1, (1, 0, 0))
     # geometries without a fused path say so (strided, spatial taps, too few voxels) and the chain falls back
     assert not ops.conv_pre_supported((2, 64, 8, 32, 32), (144, 64, 1, 3, 3), 1, (0, 1, 1))
+
+
+@pytest.mark.parametrize("n,cin,cout,thw", [(4, 144, 64, (16, 56, 56)), (22, 230, 128, (8, 28, 28)), (6, 48, 144, (16, 40, 40)),
+                                            (5, 64, 45, (16, 48, 48))],
+                         ids=["t1_like", "layer2_ragged_last_segment", "three_row_tiles", "ragged_rows_45"])
+def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
+    """Temporal 3x1x1 stride-1 convolutions through the F(2,3)-along-T kernel (conv_winot_kernel): forward (plain, with the
+    BatchNorm partial statistics) and input gradient (plain, with the fused shortcut add) against torch CPU fp64 and against
+    the direct kernel; the folded BatchNorm + ReLU prologue bit-identical to the separate pass."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib, layers
+    t, h, w = thw
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    wt = torch.randn(cout, cin, 3, 1, 1, generator=g) / np.sqrt(cin * 3)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    add = torch.randn(n, cin, t, h, w, generator=g)
+    yr = F.conv3d(x.double(), wt.double(), padding=(1, 0, 0))
+    dxr = torch.nn.grad.conv3d_input(x.shape, wt.double(), dy.double(), padding=(1, 0, 0))
+    lib = _lib.load()
+    d = ops.conv_desc(x.shape, wt.shape, 1, (1, 0, 0))
+    xd, wd, dyd, addd = x.to(DEV), wt.to(DEV), dy.to(DEV), add.to(DEV)
+
+    def fwd(want_stats):
+        y = torch.empty((n, cout, t, h, w), device=DEV)
+        nbytes = lib.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        stats, tiles = None, 0
+        if want_stats:
+            tiles = lib.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr())
+            assert tiles > 0
+            stats = torch.full((2, cout, tiles), float("nan"), device=DEV)
+        _lib.check(lib.zsv_conv3d_fwd_stats(ctypes.byref(d), xd.data_ptr(), wd.data_ptr(), None, y.data_ptr(), 0,
+                                            stats.data_ptr() if stats is not None else None, tiles, ws.data_ptr(), nbytes, None), "fwd")
+        torch.cuda.synchronize()
+        return y, stats
+
+    def dgrad(with_add):
+        dx = torch.empty((n, cin, t, h, w), device=DEV)
+        nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.zsv_conv3d_dgrad_add(ctypes.byref(d), dyd.data_ptr(), wd.data_ptr(), addd.data_ptr() if with_add else None,
+                                            dx.data_ptr(), ws.data_ptr(), nbytes, None), "dgrad")
+        torch.cuda.synchronize()
+        return dx
+
+    y, _ = fwd(False)
+    close(y, yr, what="temporal winograd fwd")
+    y2, stats = fwd(True)
+    assert torch.equal(y, y2)
+    close(stats[0].double().sum(1), yr.sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="temporal winograd fwd: sum y")
+    close(stats[1].double().sum(1), (yr * yr).sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="temporal winograd fwd: sum y^2")
+    dx = dgrad(False)
+    close(dx, dxr, what="temporal winograd dgrad")
+    close(dgrad(True), dxr + add.double(), what="temporal winograd dgrad + add")
+    # folded BatchNorm + ReLU (PRE form of this kernel) vs the separate normalise pass: same bits
+    if ops.conv_pre_supported(x.shape, wt.shape, 1, (1, 0, 0)):
+        def chain(fused):
+            bn = layers.BatchNorm3d(cin).to(DEV).train()
+            conv = layers.Conv3d(cin, cout, kernel_size=(3, 1, 1), padding=(1, 0, 0), bias=False).to(DEV)
+            conv.weight.data.copy_(wt)
+            xg = x.to(DEV).requires_grad_()
+            if fused:
+                handle, coef = bn.deferred(xg)
+                out = conv.forward_pre(handle, coef)
+            else:
+                out = conv(bn(xg, relu=True))
+            out.backward(dyd)
+            torch.cuda.synchronize()
+            return out.detach(), xg.grad, conv.weight.grad, bn.weight.grad
+        for a, b in zip(chain(True), chain(False)):
+            assert torch.equal(a, b), "folded BatchNorm differs from the separate pass"
+    monkeypatch.setenv("ZSV_NO_WINOT", "1")
+    yd, _ = fwd(False)
+    close(y, yd.double(), rtol=5e-6, what="temporal winograd vs direct kernel (fwd)")
+    close(dx, dgrad(False).double(), rtol=5e-6, what="temporal winograd vs direct kernel (dgrad)")
+    assert not torch.equal(y, yd), "the two paths should not be the same kernel"

@@ -174,10 +174,11 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
 // (Conv2Plus1D's `BatchNorm3d(mid) -> ReLU -> temporal conv`, resnet.py:46-52): both the forward (direct kernel, PRE form)
 // and the weight gradient (frame-ring kernel, PRE form) must be able to apply the affine + ReLU while they read x.
 extern "C" int32_t zsv_conv3d_pre_supported(const zsv_conv_desc* d) {
-    if (conv_check(d) != ZSV_OK || wino_fwd_applicable(d) || getenv("ZSV_NO_BN_FUSION")) return 0;
+    if (conv_check(d) != ZSV_OK || getenv("ZSV_NO_BN_FUSION") || !wgrad_tring_applicable(d, nullptr, nullptr)) return 0;
+    if (wino_fwd_applicable(d)) return wino_fwd_pre_capable(d) ? 1 : 0;          // (the temporal F(2,3)-along-T kernel)
     IgemmParams p;
     fwd_params(p, d, 0);
-    return (igemm_tap_applicable(p) && wgrad_tring_applicable(d, nullptr, nullptr)) ? 1 : 0;
+    return igemm_tap_applicable(p) ? 1 : 0;
 }
 
 extern "C" int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
@@ -189,6 +190,11 @@ extern "C" int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const 
     if (!zsv_conv3d_pre_supported(d) || coef_pitch < d->Cin || coef_pitch % 16 != 0 ||
         (reinterpret_cast<uintptr_t>(pre_coef) & 15) != 0)
         return ZSV_E_UNSUPPORTED;
+    if (wino_fwd_applicable(d)) {
+        if (bn_partials && stat_tiles != zsv_conv3d_fwd_stat_tiles(d, y)) return ZSV_E_UNSUPPORTED;
+        return wino_fwd_pre(d, x, pre_coef, coef_pitch, w, bn_partials, bn_partials ? bn_partials + (size_t)d->Cout * stat_tiles : nullptr,
+                            y, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     IgemmParams p;
     fwd_params(p, d, 0);
     p.pre_coef = pre_coef;

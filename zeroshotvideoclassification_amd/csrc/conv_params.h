@@ -191,6 +191,9 @@ size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream);
 bool wino_fwd_applicable(const zsv_conv_desc* d);
+bool wino_fwd_pre_capable(const zsv_conv_desc* d);   // the temporal F(2,3)-along-T forward: can apply a BatchNorm + ReLU prologue
+int wino_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* w, float* stat_sum,
+                 float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream);
 bool wino_fwd_fusable(const zsv_conv_desc* d);       // false: split-K form, no statistics / add / residual in the epilogue
 bool wino_dgrad_fusable(const zsv_conv_desc* d);
 int wino_fwd_stat_tiles(const zsv_conv_desc* d);

@@ -48,6 +48,11 @@ struct WinoParams {
     int relu;
     float* stat_sum;        // != nullptr: per (channel, column tile) sum and sum of squares of the raw result
     float* stat_sq;         //   [M][tiles_n] each (BatchNorm statistics of a training forward)
+    // temporal form (conv_winot_kernel): PW = 256 / T positions per tile, segs = tiles per clip; PRE: the input is read as
+    // relu(in * scale[c] + shift[c]) with pre_coef = [2][pre_pitch] (see conv_tap.hip PRE / zsv_bn_fwd_train_coeffs)
+    int PW, segs;
+    const float* pre_coef;
+    int pre_pitch;
 };
 
 // Up[(cb*R + r)*4 + pt][Mp][c%16] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
@@ -601,6 +606,224 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #endif
 }
 
+// ================================================================================================
+// Temporal 3x1x1 stride-1 "same" convolution (the second half of Conv2Plus1D, resnet.py:46-52) with the kt taps in Winograd
+// F(2,3) form ALONG T: two frames (t, t+1) of one (h, w) position share the four input frames d0..d3 = in[t-1..t+2],
+//     V = (d0-d2, d1+d2, d2-d1, d1-d3),  U as above from (g0, g1, g2) = the kt weights,  y(t) = M0+M1+M2,  y(t+1) = M1-M2-M3
+// -- 4 multiplies per output pair instead of 6, and ONE image per 16-channel block instead of one per tap: the direct kernel
+// (conv_tap.hip) gathers three frame-shifted copies of the input, which is what bounds the 64-row forward (its image DMAs cost
+// 20 % of its time, profiles/r02_tap_kernel_ablation.txt).
+// A workgroup tile is ALL T frames (T = 4, 8 or 16) of PW = 256 / T consecutive (h, w) positions of one clip: 128 frame PAIRS,
+// one 16-pair block = 16 positions of one frame pair, two blocks per wave; the image of a chunk is [16 k][T][PW] (1 KiB per k
+// row = one 16-byte DMA instruction), there is no halo: frames -1 and T are the zero padding, a wave-uniform zeroing of d0 / d3.
+// K = 16-channel blocks (9 chunks for the 144 -> 64 forward).  Epilogue as above (statistics / + add), two 4-byte stores per
+// value pair (64 contiguous bytes per row, frame and 16 lanes).  PRE as in conv_tap.hip: the BatchNorm + ReLU in front of the
+// convolution is applied to d0..d3 in registers (no per-voxel masks needed: only whole frames are padding).
+template <int TM, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, const float* __restrict__ Up,
+                                                            const float* __restrict__ IN, float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 16 * TM, BK = 16;
+    constexpr int LDB = 260;                // 256 used; 4 * LDB = 16 mod 32: the k rows 4g+s of the two lane halves of a ds_read_b32 split the banks
+    constexpr int A_FLOATS = 4 * BM * BK, B_FLOATS = BK * LDB;
+    constexpr int COEF_AT = A_FLOATS + B_FLOATS;        // PRE: 1 KiB DMA target, 32 floats used (16 scales, 16 shifts)
+    constexpr int STAGE = COEF_AT + (PRE ? 256 : 0);
+    constexpr unsigned OOB16 = 0xFFFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float pool[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);          // the row tiles of one column tile are neighbours (one L2)
+    const int m0 = (tile % prm.tiles_m) * BM;
+    const int ct = tile / prm.tiles_m;                          // column tile = (clip, position segment)
+    const int n_img = ct / prm.segs, pos0 = (ct - n_img * prm.segs) * prm.PW;
+    const int T = prm.T, PW = prm.PW, HW = prm.HW;
+    const int pq = PW >> 2;                                     // 16-byte pieces per frame row
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
+    const int ch_bytes = 4 * prm.S;
+    // this lane's 16-byte piece of every k row: frame lane / pq, positions pos0 + 4 * (lane % pq) ..
+    const int pf = lane / pq, pp = pos0 + 4 * (lane - pf * pq);
+    const unsigned piece_off = pp < HW ? (unsigned)(4 * (n_img * prm.C * prm.S + pf * HW + pp)) : OOB16;
+
+    constexpr int APASS = TM;
+    const float* a_src[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int q = wave + 4 * j, pt = q / TM, ib = q % TM, row = lane >> 2;
+        const int sw = ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 4;
+        a_src[j] = Up + ((size_t)pt * prm.Mp + m0 + 16 * ib + row) * 16 + sw;
+    }
+    const size_t a_chunk_stride = (size_t)4 * BK * prm.Mp;
+    const __amdgpu_buffer_rsrc_t pre_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? prm.pre_coef : IN), 0, PRE ? 8u * (unsigned)prm.pre_pitch : 0u, 0x00020000);
+
+    const int nchunks = prm.nblk;
+    auto issue = [&](int chunk, int buf) {
+        float* as = pool + buf * STAGE;
+        float* bs = as + A_FLOATS;
+        const int ci0 = chunk * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB), 16, (int)(ci < prm.C ? piece_off : OOB16),
+                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j)
+            __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * (wave + 4 * j)), 16, 0, 0);
+        if constexpr (PRE) {
+            if (wave == 0) {
+                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : OOB16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(as + COEF_AT), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[4][TM][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    // this wave's two 16-pair blocks: block b = 2 * wave + j = (frame pair b / (PW/16), 16-position group b % (PW/16))
+    int col_of[2], tp_of[2];
+    bool zero_d0[2], zero_d3[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int b = 2 * wave + j, groups = PW >> 4;
+        tp_of[j] = b / groups;
+        col_of[j] = 16 * (b - tp_of[j] * groups) + r16;            // position inside the tile
+        zero_d0[j] = tp_of[j] == 0;                                  // frame -1
+        zero_d3[j] = 2 * tp_of[j] + 2 >= T;                          // frame T
+    }
+
+    issue(0, 0);
+    __syncthreads();                                   // (vmcnt(0) before the barrier)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        const float* as = pool + cur * STAGE;
+        const float* bs = as + A_FLOATS;
+        f32x4 a4[4][TM];
+        const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
+        float psc[PRE ? 4 : 1], psh[PRE ? 4 : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                psc[s] = as[COEF_AT + 4 * g + s];
+                psh[s] = as[COEF_AT + 16 + 4 * g + s];
+            }
+        }
+        float raw[2][2][4];
+        auto fetch = [&](int s, int slot) {
+            const float* row = bs + (4 * g + s) * LDB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int f0 = 2 * tp_of[j] - 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = min(max(f0 + i, 0), T - 1);       // (clamped: the out-of-clip frames are zeroed below)
+                    raw[slot][j][i] = row[f * PW + col_of[j]];
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sl = s & 1;
+            float v[4][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d[i] = raw[sl][j][i];
+                    if constexpr (PRE) d[i] = fmaxf(__fmaf_rn(d[i], psc[s], psh[s]), 0.f);
+                }
+                const float d0 = zero_d0[j] ? 0.f : d[0], d3 = zero_d3[j] ? 0.f : d[3];
+                v[0][j] = d0 - d[2]; v[1][j] = d[1] + d[2]; v[2][j] = d[2] - d[1]; v[3][j] = d[1] - d3;
+            }
+            if (s < 3) fetch(s + 1, sl ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p][j], acc[p][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                               // (vmcnt(0) lgkmcnt(0) + barrier)
+    }
+
+    // ---- output transform (+ statistics) (+ add) + store: lane holds rows 4g..4g+3 of pair column r16 of its two blocks
+    const bool stats = prm.stat_sum != nullptr;
+    float* red = pool;
+    if (stats) __syncthreads();
+    int off0[2];
+    bool ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int pos = pos0 + col_of[j];
+        ok[j] = pos < HW;
+        off0[j] = n_img * prm.M * prm.S + 2 * tp_of[j] * HW + pos;     // frame 2*tp; frame 2*tp+1 is HW further
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * i + 4 * g + r;
+            const int row_off = m * prm.S;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float M0 = acc[0][i][j][r], M1 = acc[1][i][j][r], M2 = acc[2][i][j][r], M3 = acc[3][i][j][r];
+                float y0 = (M0 + M1) + M2, y1 = (M1 - M2) - M3;
+                if (ok[j] && m < prm.M) {
+                    s1 += y0 + y1;
+                    s2 += y0 * y0 + y1 * y1;
+                    const int off = off0[j] + row_off;
+                    if (prm.add != nullptr) { y0 += prm.add[off]; y1 += prm.add[off + HW]; }
+                    OUT[off] = y0;
+                    OUT[off + HW] = y1;
+                }
+            }
+            if (stats) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (r16 == 0) {
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2] = s1;
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < prm.M) {
+            const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
+            const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
+            prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + ct] = t1;
+            prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + ct] = t2;
+        }
+    }
+#endif
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -612,7 +835,9 @@ static int wino_tm(int M) {
 
 // K parts: 1 when the tiles alone fill the two-workgroups-per-CU round, else 2..4 parts of >= 12 chunks each that do
 // (their raw partial results go to slabs, summed by splitk_reduce); 0 = too few tiles either way: the direct kernel
+static bool winot_geometry(const zsv_conv_desc* d, int M);
 static int wino_ksplit(const zsv_conv_desc* d, int M) {
+    if (winot_geometry(d, M)) return 1;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     const int bm = 16 * wino_tm(M), C = M == d->Cout ? d->Cin : d->Cout;
     const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256), nchunks = (long)((C + 15) / 16) * 3 * d->kT;
@@ -625,7 +850,28 @@ static int wino_ksplit(const zsv_conv_desc* d, int M) {
     return 0;
 }
 
+// temporal 3x1x1 stride-1 "same" convolution on the F(2,3)-along-T kernel: T = 4, 8, 16 whole clips per tile, 16-byte pieces,
+// one round of workgroups at least (no K parts: the K loop is only Cin / 16 chunks)
+static bool winot_shape(const zsv_conv_desc* d) {
+    return d->kT == 3 && d->kH == 1 && d->kW == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 0 && d->pW == 0;
+}
+static int winot_segs(const zsv_conv_desc* d) {
+    const int PW = 256 / d->Ti;
+    return (d->Hi * d->Wi + PW - 1) / PW;
+}
+static bool winot_geometry(const zsv_conv_desc* d, int M) {
+    if (getenv("ZSV_NO_WINO") || getenv("ZSV_NO_WINOT") || !winot_shape(d)) return false;
+    if ((d->Ti != 4 && d->Ti != 8 && d->Ti != 16) || (d->Hi * d->Wi) % 4 != 0 || d->Cin < 16 || d->Cout < 16) return false;
+    const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
+    if ((long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
+    const int bm = 16 * wino_tm(M);
+    const long tiles = (long)((M + bm - 1) / bm) * d->N * winot_segs(d);
+    const long hw = (long)d->Hi * d->Wi, covered = (long)winot_segs(d) * (256 / d->Ti);
+    return tiles >= 512 && covered * 10 <= hw * 11;                 // at most 10 % of empty positions in the last segment
+}
+
 static bool wino_geometry(const zsv_conv_desc* d, int M) {
+    if (winot_geometry(d, M)) return true;
     if (getenv("ZSV_NO_WINO")) return false;
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
         d->pH != 1 || d->pW != 1)
@@ -642,12 +888,17 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
 // dgrad / forward of a 1x3x3 or 3x3x3 stride-1 "same" convolution with enough voxel tiles to fill the chip
 bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cin); }
 bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
-int wino_fwd_stat_tiles(const zsv_conv_desc* d) { return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256); }
+int wino_fwd_stat_tiles(const zsv_conv_desc* d) {
+    if (winot_geometry(d, d->Cout)) return d->N * winot_segs(d);
+    return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256);
+}
 
 // W % 4 == 0: the F(4,3) kernel (6 Winograd points), else F(2,3) (4 points)
 static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_F43") == nullptr; }
 static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
-    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16, points = wino_f43(d) ? 6 : 4;
+    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
+    if (winot_shape(d)) return wino_align((size_t)nblk * 4 * 16 * Mp * sizeof(float));            // (no row taps)
+    const int points = wino_f43(d) ? 6 : 4;
     return wino_align((size_t)nblk * 3 * d->kT * points * 16 * Mp * sizeof(float));
 }
 // transformed weights + (split-K) the parts' slabs
@@ -681,6 +932,47 @@ static int wino4_launch(const WinoParams& p, const float* up, const float* in, f
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
     hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
+}
+
+template <int TM, bool PRE>
+static int winot_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    constexpr int LDS_BYTES = 2 * (4 * 16 * TM * 16 + 16 * 260 + (PRE ? 256 : 0)) * 4;          // as in the kernel
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_winot_kernel<TM, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    hipLaunchKernelGGL((conv_winot_kernel<TM, PRE>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    return launch_status();
+}
+
+// the temporal form: M rows from C reduction channels; G[m][c][kt] = w[m*sm + c*sc + (flip ? 2 - kt : kt)]
+static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
+                     const float* add, float* stat_sum, float* stat_sq, const float* pre_coef, int pre_pitch, float* out,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!workspace || workspace_bytes < wino_bytes(d, M, C)) return ZSV_E_WORKSPACE;
+    const int tm = wino_tm(M), bm = 16 * tm;
+    WinoParams p;
+    p.M = M;
+    p.Mp = (M + bm - 1) / bm * bm;
+    p.C = C;
+    p.nblk = (C + 15) / 16;
+    p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi; p.H = d->Hi; p.T = d->Ti;
+    p.kT = 3; p.R = 1;
+    p.P = d->N * p.S;
+    p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
+    p.PW = 256 / d->Ti;
+    p.segs = winot_segs(d);
+    p.tiles_m = p.Mp / bm;
+    p.tiles_n = d->N * p.segs;
+    p.add = add; p.bias = nullptr; p.relu = 0; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
+    p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
+    float* up = (float*)workspace;
+    const long total = (long)p.nblk * 4 * 16 * p.Mp;
+    long pb = (total + 255) / 256;
+    if (pb > 4096) pb = 4096;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip, total);
+    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (pre_coef) return tm == 3 ? winot_launch<3, true>(p, up, in, out, stream) : winot_launch<4, true>(p, up, in, out, stream);
+    return tm == 3 ? winot_launch<3, false>(p, up, in, out, stream) : winot_launch<4, false>(p, up, in, out, stream);
 }
 
 // out[m] = sum_c G[m][c] (*) in[c]; G[m][c][tap] = w[m*sm + c*sc + (flip ? 9*kT-1 - tap : tap)]
@@ -736,14 +1028,32 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
 
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream) {
+    if (winot_geometry(d, d->Cin))          // G[m = ci][c = co][kt] = W[co][ci][2 - kt]
+        return winot_run(d, d->Cin, d->Cout, dy, w, 3, (long)d->Cin * 3, 1, add, nullptr, nullptr, nullptr, 0, dx, workspace,
+                         workspace_bytes, stream);
     // G[m = ci][c = co][kt][kh][kw] = W[co][ci][kT-1-kt][2-kh][2-kw]: stride of m is 9*kT, of c is Cin*9*kT, taps flipped
     const long taps = 9L * d->kT;
     return wino_run(d, d->Cin, d->Cout, dy, w, taps, (long)d->Cin * taps, 1, add, nullptr, 0, nullptr, nullptr, dx, workspace,
                     workspace_bytes, stream);
 }
 
+bool wino_fwd_pre_capable(const zsv_conv_desc* d) { return winot_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
+
+// the temporal forward with the BatchNorm + ReLU in front of it applied on the fly (conv_winot_kernel PRE)
+int wino_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* w, float* stat_sum,
+                 float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!wino_fwd_pre_capable(d)) return ZSV_E_UNSUPPORTED;
+    return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, nullptr, stat_sum, stat_sq, pre_coef, pre_pitch, y, workspace,
+                     workspace_bytes, stream);
+}
+
 int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,
              float* stat_sum, float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (winot_geometry(d, d->Cout)) {
+        if (bias || relu) return ZSV_E_UNSUPPORTED;
+        return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, residual, stat_sum, stat_sq, nullptr, 0, y, workspace,
+                         workspace_bytes, stream);
+    }
     const long taps = 9L * d->kT;
     return wino_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * taps, taps, 0, residual, bias, relu, stat_sum, stat_sq, y, workspace,
                     workspace_bytes, stream);
