@@ -795,6 +795,8 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
                     s2 += y0 * y0 + y1 * y1;
                     const int off = off0[j] + row_off;
                     if (prm.add != nullptr) { y0 += prm.add[off]; y1 += prm.add[off + HW]; }
+                    if (prm.bias != nullptr) { const float bv = prm.bias[m]; y0 += bv; y1 += bv; }
+                    if (prm.relu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
                     OUT[off] = y0;
                     OUT[off + HW] = y1;
                 }
@@ -945,7 +947,8 @@ static int winot_launch(const WinoParams& p, const float* up, const float* in, f
 
 // the temporal form: M rows from C reduction channels; G[m][c][kt] = w[m*sm + c*sc + (flip ? 2 - kt : kt)]
 static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
-                     const float* add, float* stat_sum, float* stat_sq, const float* pre_coef, int pre_pitch, float* out,
+                     const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, const float* pre_coef,
+                     int pre_pitch, float* out,
                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!workspace || workspace_bytes < wino_bytes(d, M, C)) return ZSV_E_WORKSPACE;
     const int tm = wino_tm(M), bm = 16 * tm;
@@ -962,7 +965,7 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.segs = winot_segs(d);
     p.tiles_m = p.Mp / bm;
     p.tiles_n = d->N * p.segs;
-    p.add = add; p.bias = nullptr; p.relu = 0; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
     p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
     float* up = (float*)workspace;
@@ -1029,7 +1032,7 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
                size_t workspace_bytes, hipStream_t stream) {
     if (winot_geometry(d, d->Cin))          // G[m = ci][c = co][kt] = W[co][ci][2 - kt]
-        return winot_run(d, d->Cin, d->Cout, dy, w, 3, (long)d->Cin * 3, 1, add, nullptr, nullptr, nullptr, 0, dx, workspace,
+        return winot_run(d, d->Cin, d->Cout, dy, w, 3, (long)d->Cin * 3, 1, add, nullptr, 0, nullptr, nullptr, nullptr, 0, dx, workspace,
                          workspace_bytes, stream);
     // G[m = ci][c = co][kt][kh][kw] = W[co][ci][kT-1-kt][2-kh][2-kw]: stride of m is 9*kT, of c is Cin*9*kT, taps flipped
     const long taps = 9L * d->kT;
@@ -1043,17 +1046,15 @@ bool wino_fwd_pre_capable(const zsv_conv_desc* d) { return winot_geometry(d, d->
 int wino_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* w, float* stat_sum,
                  float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!wino_fwd_pre_capable(d)) return ZSV_E_UNSUPPORTED;
-    return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, nullptr, stat_sum, stat_sq, pre_coef, pre_pitch, y, workspace,
+    return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, nullptr, nullptr, 0, stat_sum, stat_sq, pre_coef, pre_pitch, y, workspace,
                      workspace_bytes, stream);
 }
 
 int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float* bias, const float* residual, int relu,
              float* stat_sum, float* stat_sq, float* y, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (winot_geometry(d, d->Cout)) {
-        if (bias || relu) return ZSV_E_UNSUPPORTED;
-        return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, residual, stat_sum, stat_sq, nullptr, 0, y, workspace,
-                         workspace_bytes, stream);
-    }
+    if (winot_geometry(d, d->Cout))
+        return winot_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * 3, 3, 0, residual, bias, relu, stat_sum, stat_sq, nullptr, 0, y,
+                         workspace, workspace_bytes, stream);
     const long taps = 9L * d->kT;
     return wino_run(d, d->Cout, d->Cin, x, w, (long)d->Cin * taps, taps, 0, residual, bias, relu, stat_sum, stat_sq, y, workspace,
                     workspace_bytes, stream);
