@@ -869,7 +869,10 @@ static bool winot_geometry(const zsv_conv_desc* d, int M) {
     const int bm = 16 * wino_tm(M);
     const long tiles = (long)((M + bm - 1) / bm) * d->N * winot_segs(d);
     const long hw = (long)d->Hi * d->Wi, covered = (long)winot_segs(d) * (256 / d->Ti);
-    return tiles >= 512 && covered * 10 <= hw * 11;                 // at most 10 % of empty positions in the last segment
+    const char* e1 = getenv("ZSV_WINOT_MIN_TILES");
+    const char* e2 = getenv("ZSV_WINOT_MAX_WASTE");
+    const long min_tiles = e1 ? atol(e1) : 256, max_waste = e2 ? atol(e2) : 35;      // (layer3's 14x14 maps: 196 of 256 positions, 352 tiles: still +15 %)
+    return tiles >= min_tiles && covered * 100 <= hw * (100 + max_waste);     // few empty positions in the last segment
 }
 
 static bool wino_geometry(const zsv_conv_desc* d, int M) {
