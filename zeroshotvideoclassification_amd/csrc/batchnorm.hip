@@ -153,6 +153,41 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C,
     shift[c] = __fmaf_rn(-(float)mean, sc, bt);      // (the backward recomputes exactly this)
 }
 
+// Statistics from the producing convolution's epilogue partials and the finalisation in ONE launch (a block per channel): the
+// reduce of bn_partials_reduce_kernel followed by exactly bn_finalize_train_kernel's arithmetic (pivot 0).
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                                   int C, int tiles, double count, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                                   float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var, float momentum, float eps,
+                                                                   float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+        a1 += (double)psum[(size_t)c * tiles + t];
+        a2 += (double)psq[(size_t)c * tiles + t];
+    }
+    const double s1 = block_sum_256<double>(a1, red);
+    const double s2 = block_sum_256<double>(a2, red);
+    if (threadIdx.x != 0) return;
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    const float sc = g * (float)invstd;
+    scale[c] = sc;
+    shift[c] = __fmaf_rn(-(float)mean, sc, bt);
+}
+
 __global__ void bn_eval_coeff_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                      float* __restrict__ scale, float* __restrict__ shift) {
@@ -427,18 +462,18 @@ extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int3
     BnWs w = bn_ws(workspace, C, slices);
     const float* pivot_src = x;
     if (conv_partials && stat_tiles > 0) {
-        pivot_src = nullptr;        // the epilogue sums are unshifted (bias-free convolution outputs: |mean| ~ std)
-        // statistics were accumulated by the producing convolution's epilogue: no pass over x
-        hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
-                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, w.part);
-        slices = 1;
+        // statistics were accumulated by the producing convolution's epilogue (unshifted sums: bias-free convolution outputs,
+        // |mean| ~ std): no pass over x, reduce + finalise in one launch
+        hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
+                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, (double)N * S, gamma, beta, save_mean, save_invstd,
+                           running_mean, running_var, momentum, eps, w.scale, w.shift);
     } else {
         hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+        if ((st = launch_status())) return st;
+        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
+                           slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
+                           momentum, eps, w.scale, w.shift);
     }
-    if ((st = launch_status())) return st;
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
-                       slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
-                       momentum, eps, w.scale, w.shift);
     if ((st = launch_status())) return st;
     return launch_apply(x, residual, y, N, C, S, w.scale, w.shift, fuse_relu, stream);
 }
@@ -460,16 +495,15 @@ extern "C" int zsv_bn_fwd_train_coeffs(const float* x, int32_t N, int32_t C, int
     int slices = bn_slices(N, C, S);
     BnWs w = bn_ws(workspace, C, slices);
     const float* pivot_src = x;
-    if (conv_partials && stat_tiles > 0) {
-        pivot_src = nullptr;
-        hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
-                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, w.part);
-        slices = 1;
-    } else {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
-    }
-    if ((st = launch_status())) return st;
     if (coef_pitch > C && hipMemsetAsync(coef, 0, (size_t)2 * coef_pitch * sizeof(float), stream) != hipSuccess) return ZSV_E_LAUNCH;
+    if (conv_partials && stat_tiles > 0) {
+        hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, stream, conv_partials,
+                           conv_partials + (size_t)C * stat_tiles, C, stat_tiles, (double)N * S, gamma, beta, save_mean, save_invstd,
+                           running_mean, running_var, momentum, eps, coef, coef + coef_pitch);
+        return launch_status();
+    }
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
+    if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
                        slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
                        momentum, eps, coef, coef + coef_pitch);
