@@ -103,21 +103,6 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-// conv-epilogue partials [C][tiles] (sum) and [C][tiles] (sum of squares) -> part[2][C][1] in fp64
-__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
-                                                                 int C, int tiles, double* __restrict__ part) {
-    __shared__ double red[4];
-    const int c = blockIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = threadIdx.x; t < tiles; t += 256) {
-        s1 += (double)psum[(size_t)c * tiles + t];
-        s2 += (double)psq[(size_t)c * tiles + t];
-    }
-    const double t1 = block_sum_256<double>(s1, red);
-    const double t2 = block_sum_256<double>(s2, red);
-    if (threadIdx.x == 0) { part[c] = t1; part[C + c] = t2; }
-}
-
 // `pivot_src` (may be null = pivot 0): the tensor bn_stats_kernel shifted by x[c * S]; the partial sums are then
 // sums of (x - K) and (x - K)^2.
 __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C, int slices, double count,
@@ -153,8 +138,9 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C,
     shift[c] = __fmaf_rn(-(float)mean, sc, bt);      // (the backward recomputes exactly this)
 }
 
-// Statistics from the producing convolution's epilogue partials and the finalisation in ONE launch (a block per channel): the
-// reduce of bn_partials_reduce_kernel followed by exactly bn_finalize_train_kernel's arithmetic (pivot 0).
+// Statistics from the producing convolution's epilogue partials ([C][tiles] sums and [C][tiles] sums of squares, fp32) and the
+// finalisation in ONE launch (a block per channel): a double-precision block sum in a fixed order, then exactly
+// bn_finalize_train_kernel's arithmetic with pivot 0.
 __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
                                                                    int C, int tiles, double count, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ save_mean,
