@@ -506,3 +506,24 @@ def test_folded_batchnorm_is_the_same_bits_at_model_level(monkeypatch):
         assert torch.equal(ga[k], gb[k]), k
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_gradient_accumulation_with_the_wgrad_side_stream():
+    """`zero_grad(set_to_none=False)` / two backward passes into the same `.grad`: autograd then adds each weight gradient
+    in place on the backward stream, which must wait for the side stream that computed it."""
+    g, model, weights = build("r2plus1d_small")
+    x, z = case_inputs(g)
+    xd, zd = x.to(DEV), z.to(DEV)
+    model.load_state_dict(weights)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    F.mse_loss(train.embed(model, xd), zd).backward()
+    once = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.load_state_dict(weights)
+    F.mse_loss(train.embed(model, xd), zd).backward()            # accumulates into the existing .grad
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        if p.grad is not None and "running" not in k:
+            ref = once[k] * 2
+            err = (p.grad - ref).abs().max().item()
+            assert err <= 1e-5 * (ref.abs().max().item() + 1e-12), (k, err)

@@ -67,7 +67,7 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 # profiles/r02_wgrad_side_stream_ab.txt; gradients are bit-identical, the kernels are the same).  The autograd engine runs a callback at the end of the backward pass that makes
 # the calling stream wait for the side stream, so `.grad` is safe to read right after `loss.backward()`.
 _WGRAD_SIDE = {}
-_WGRAD_JOIN_QUEUED = set()
+_WGRAD_JOIN_QUEUED = {}
 
 
 def wgrad_side_stream(device):
@@ -88,8 +88,10 @@ def join_wgrad_streams(stream=None):
             (stream or torch.cuda.current_stream()).wait_stream(st)
 
 
-def _on_wgrad_stream(launch, inputs):
-    """Run ``launch(stream_handle) -> dw`` on the weight-gradient side stream (or the current stream when it is disabled)."""
+def _on_wgrad_stream(launch, inputs, param=None):
+    """Run ``launch(stream_handle) -> dw`` on the weight-gradient side stream (or the current stream when it is disabled).
+    ``param``: the parameter the gradient belongs to -- when it already holds a ``.grad`` (``zero_grad(set_to_none=False)``,
+    gradient accumulation) autograd adds ``dw`` to it in place on the backward stream right away, so that stream must wait."""
     dev = inputs[-1].device
     side = wgrad_side_stream(dev)
     if side is None:
@@ -103,22 +105,24 @@ def _on_wgrad_stream(launch, inputs):
     for t in inputs:
         t.record_stream(side)                          # the side stream reads memory the backward stream owns
     dw.record_stream(main)                             # ... and the optimizer reads dw on the backward stream
+    if param is not None and getattr(param, "grad", None) is not None:
+        main.wait_stream(side)                         # accumulated in place by autograd as soon as this function returns
     _queue_wgrad_join(dev)
     return dw
 
 
 def _queue_wgrad_join(device):
+    """Once per backward pass (autograd graph task) and device: a callback that runs when the pass ends and makes the
+    stream the pass was launched on wait for the weight-gradient stream.  Keyed by the graph task id, so a pass that died
+    with an exception cannot leave a stale "already queued" mark behind."""
     key = torch.device(device).index
-    if key in _WGRAD_JOIN_QUEUED:
+    task = torch._C._current_graph_task_id()
+    if _WGRAD_JOIN_QUEUED.get(key) == task and task != -1:
         return
-    _WGRAD_JOIN_QUEUED.add(key)
+    _WGRAD_JOIN_QUEUED[key] = task
     main = torch.cuda.current_stream(device)
-
-    def _join():
-        _WGRAD_JOIN_QUEUED.discard(key)
-        main.wait_stream(_WGRAD_SIDE[key])
-
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
+    side = _WGRAD_SIDE[key]
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
 
 
 class KernelTimer:
@@ -268,7 +272,7 @@ class _Conv3d(Function):
                                                     stream), "zsv_conv3d_wgrad")
                     return out
 
-                dw = _on_wgrad_stream(launch, (x, dy))
+                dw = _on_wgrad_stream(launch, (x, dy), weight)
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = channel_sum(dy)
         return dx, dw, db, None, None, None, None, None
@@ -512,7 +516,7 @@ class _Conv3dPre(Function):
                                                         out.data_ptr(), _ptr(ws), nbytes, stream), "zsv_conv3d_wgrad_pre")
                     return out
 
-                dw = _on_wgrad_stream(launch, (x, coef, dy))
+                dw = _on_wgrad_stream(launch, (x, coef, dy), weight)
         return dx, None, dw, None, None, None
 
 
