@@ -82,6 +82,8 @@ def launch_children(n_gpus: int, argv) -> int:
     0's stdout -- the one JSON line -- is this process's stdout.  Non-zero exit if any rank fails."""
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get("ZSV_BENCH_SAME_DEVICE"):          # rehearsal on a one-GPU box: every rank on cuda:0, gloo transport
+        have = max(have, n_gpus)
     if have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
         return 2
@@ -206,11 +208,19 @@ def main():
     from zeroshotvideoclassification_amd import _lib, ddp, network, ops, optim, synthetic, train
     from types import SimpleNamespace
     _lib.load()
+    # (rehearsal knobs for a one-GPU box: ZSV_BENCH_SAME_DEVICE=1 puts every rank on cuda:0, ZSV_BENCH_BACKEND=gloo replaces RCCL,
+    # which needs one device per rank; the numbers of such a run mean nothing, the code path is the point)
+    if os.environ.get("ZSV_BENCH_SAME_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("ZSV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(0)
     model = network.get_network(SimpleNamespace(network=args.network, fixconvs=False, nopretrained=False))
