@@ -840,8 +840,9 @@ def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, 
 
 
 @pytest.mark.parametrize("n,cin,cout,thw", [(4, 144, 64, (16, 56, 56)), (22, 230, 128, (8, 28, 28)), (6, 48, 144, (16, 40, 40)),
-                                            (5, 64, 45, (16, 48, 48))],
-                         ids=["t1_like", "layer2_ragged_last_segment", "three_row_tiles", "ragged_rows_45"])
+                                            (5, 64, 45, (16, 48, 48)), (22, 128, 256, (4, 14, 14)), (3, 20, 70, (8, 60, 60))],
+                         ids=["t1_like", "layer2_ragged_last_segment", "three_row_tiles", "ragged_rows_45", "layer3_t4_partial_tiles",
+                              "ragged_k_20_channels"])
 def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
     """Temporal 3x1x1 stride-1 convolutions through the F(2,3)-along-T kernel (conv_winot_kernel): forward (plain, with the
     BatchNorm partial statistics) and input gradient (plain, with the fused shortcut add) against torch CPU fp64 and against
@@ -891,7 +892,8 @@ def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
     close(stats[1].double().sum(1), (yr * yr).sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="temporal winograd fwd: sum y^2")
     dx = dgrad(False)
     close(dx, dxr, what="temporal winograd dgrad")
-    close(dgrad(True), dxr + add.double(), what="temporal winograd dgrad + add")
+    if lib.zsv_conv3d_dgrad_add_supported(ctypes.byref(d)):          # (not where the dgrad runs in K parts on the direct kernel)
+        close(dgrad(True), dxr + add.double(), what="temporal winograd dgrad + add")
     # folded BatchNorm + ReLU (PRE form of this kernel) vs the separate normalise pass: same bits
     if ops.conv_pre_supported(x.shape, wt.shape, 1, (1, 0, 0)):
         def chain(fused):
@@ -913,4 +915,4 @@ def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
     yd, _ = fwd(False)
     close(y, yd.double(), rtol=5e-6, what="temporal winograd vs direct kernel (fwd)")
     close(dx, dgrad(False).double(), rtol=5e-6, what="temporal winograd vs direct kernel (dgrad)")
-    assert not torch.equal(y, yd), "the two paths should not be the same kernel"
+    assert not torch.equal(y, yd), "the two paths should not be the same kernel (forward)"
