@@ -916,3 +916,62 @@ def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
     close(y, yd.double(), rtol=5e-6, what="temporal winograd vs direct kernel (fwd)")
     close(dx, dgrad(False).double(), rtol=5e-6, what="temporal winograd vs direct kernel (dgrad)")
     assert not torch.equal(y, yd), "the two paths should not be the same kernel (forward)"
+
+
+S2_DGRAD_CASES = [
+    # name, N, Cin, Cout, (T, H, W) of x, kind
+    ("s2_like", 3, 64, 230, (8, 56, 56), "hw"),
+    ("s5_like", 4, 128, 460, (8, 28, 28), "hw"),
+    ("s8_full_size_k_parts", 22, 256, 921, (4, 14, 14), "hw"),
+    ("ragged_rows_and_k", 3, 70, 37, (3, 10, 12), "hw"),
+    ("long_rows", 2, 16, 24, (2, 6, 254), "hw"),
+    ("one_clip_one_frame", 1, 16, 8, (1, 2, 2), "hw"),
+    ("t2_like", 3, 230, 128, (16, 28, 28), "t"),
+    ("t8_full_size_k_parts", 22, 921, 512, (4, 7, 7), "t"),
+    ("temporal_ragged", 3, 50, 19, (6, 5, 7), "t"),
+    ("temporal_two_frames", 2, 16, 16, (2, 3, 3), "t"),
+]
+
+
+@pytest.mark.parametrize("case", S2_DGRAD_CASES, ids=[c[0] for c in S2_DGRAD_CASES])
+def test_conv3d_stride2_dgrad_all_classes_in_one_launch(case, monkeypatch):
+    """Input gradient of Conv2Plus1D's strided convolutions (1x3x3 stride (1,2,2), 3x1x1 stride (2,1,1); resnet.py:40-52 with
+    the strides of :217-220) through conv_dgrad_s2.hip -- every residue class of input voxels in one launch -- against torch
+    CPU fp64 and against the class-by-class launches of the direct kernel, for both tile widths and with the K range cut
+    into parts."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    name, n, cin, cout, (t, h, w), kind = case
+    k, s, p = ((1, 3, 3), (1, 2, 2), (0, 1, 1)) if kind == "hw" else ((3, 1, 1), (2, 1, 1), (1, 0, 0))
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+    d = ops.conv_desc((n, cin, t, h, w), wt.shape, s, p)
+    dy = torch.randn(n, cout, d.To, d.Ho, d.Wo, generator=g)
+    ref = torch.nn.grad.conv3d_input((n, cin, t, h, w), wt.double(), dy.double(), stride=s, padding=p)
+    lib = _lib.load()
+    dy_d, wt_d = dy.to(DEV), wt.to(DEV)
+
+    def run():
+        dx = torch.full((n, cin, t, h, w), float("nan"), device=DEV)          # every voxel must be written
+        nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.zsv_conv3d_dgrad(ctypes.byref(d), dy_d.data_ptr(), wt_d.data_ptr(), dx.data_ptr(), ws.data_ptr(), nbytes,
+                                        None), "dgrad")
+        torch.cuda.synchronize()
+        return dx
+
+    merged = run()
+    close(merged, ref, what=f"{name}: merged-class dgrad")
+    assert torch.equal(merged, run()), "bitwise reproducible"
+    for bn in ("64", "128"):
+        for ks in ("1", "2", "3"):
+            monkeypatch.setenv("ZSV_DGRAD_S2_BN", bn)
+            monkeypatch.setenv("ZSV_DGRAD_S2_KS", ks)
+            close(run(), ref, what=f"{name}: tile width {bn}, {ks} K parts")
+    monkeypatch.delenv("ZSV_DGRAD_S2_BN")
+    monkeypatch.delenv("ZSV_DGRAD_S2_KS")
+    monkeypatch.setenv("ZSV_NO_DGRAD_S2", "1")
+    per_class = run()
+    close(merged, per_class.double(), rtol=5e-6, what=f"{name}: merged vs class-by-class launches")
+    if cout >= 32:                                          # (short sums can round identically)
+        assert not torch.equal(merged, per_class), "the two paths should not be the same kernel"

@@ -241,6 +241,7 @@ static int dgrad_plan(const zsv_conv_desc* d, size_t& wbytes) {
 extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
     if (wino_dgrad_applicable(d)) return wino_dgrad_workspace_bytes(d);
+    if (dgrad_s2_applicable(d)) return dgrad_s2_workspace_bytes(d);
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const size_t out_elems = (size_t)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -269,6 +270,7 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
     if (!dy || !w || !dx) return ZSV_E_NULL;
     if (add != nullptr && !zsv_conv3d_dgrad_add_supported(d)) return ZSV_E_UNSUPPORTED;
     if (wino_dgrad_applicable(d)) return wino_dgrad(d, dy, w, add, dx, workspace, workspace_bytes, (hipStream_t)stream);
+    if (dgrad_s2_applicable(d)) return dgrad_s2(d, dy, w, dx, workspace, workspace_bytes, (hipStream_t)stream);     // (stride 2: no `add`)
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
