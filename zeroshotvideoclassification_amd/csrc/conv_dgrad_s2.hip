@@ -26,6 +26,9 @@
 namespace zsv {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef S2ABL
+#define S2ABL 0        // timing-only ablation builds (tools/variant.sh): 1 no DMAs after the first chunk, 2 no fragment reads, 4 no chunk-end wait / barrier, 8 no stores
+#endif
 
 struct DgradS2Params {
     int M, Mp, tiles_m;      // rows: dx channels (Cin), padded to whole 64-row tiles
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
+        if (ch + 1 < nchunks && !(S2ABL & 1)) issue(c_first + ch + 1, cur ^ 1);
         const float* as = pool + cur * STAGE;
         const float* bs = as + A_FLOATS;
         float a[2][NTAP][TM], b[2][NSH][TN];
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
                 }
             }
         };
-        fetch(0, 0);
+        if (!(S2ABL & 2) || ch == 0) fetch(0, 0);
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             const int sl = ks & 1;
-            if (ks + 1 < BK / 4) fetch(ks + 1, sl ^ 1);
+            if (ks + 1 < BK / 4 && (!(S2ABL & 2) || ch == 0)) fetch(ks + 1, sl ^ 1);
             mask(sl);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
@@ -199,9 +202,12 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(S2ABL & 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
+    if ((S2ABL & 8) && prm.P > 0) return;
 
     // ---- epilogue: acc[cls][i][j][r]: row m0 + wm0 + 16 i + 4 g + r, dy voxel n0 + wn0 + 16 j + r16
 #pragma unroll

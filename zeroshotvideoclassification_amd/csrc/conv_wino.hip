@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     }
 }
 
+#ifndef W4ABL
+#define W4ABL 0        // timing-only ablation builds (tools/variant.sh): 1 no DMAs after the first chunk, 2 no fragment reads, 4 no chunk-end wait / barrier, 8 no stores
+#endif
 template <int TM, int NCHUNKS>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, const float* __restrict__ Up,
                                                             const float* __restrict__ IN, float* __restrict__ OUT) {
@@ -505,17 +508,20 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (!USINGLE && ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
+        if (!USINGLE && ch + 1 < nchunks && !(W4ABL & 1)) issue(c_first + ch + 1, cur ^ 1);
         const float* as = u_of(cur);
         const float* bs = img_of(cur);
         f32x4 a4[NP][TM];
+        if (!(W4ABL & 2) || ch == 0) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
+        }
         float dl[2], dr[2];
         f32x4 dm[2];
         auto fetch = [&](int s, int slot) {
+            if ((W4ABL & 2) && ch > 0) return;
             const float* src = bs + (4 * g + s) * LDB + C0 + 64 * wave + 4 * r16;        // image column of d1
             dl[slot] = src[-1];
             dm[slot] = *reinterpret_cast<const f32x4*>(src);
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         fetch(0, 0);
         if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
             __syncthreads();
-            if (ch + 1 < nchunks) issue(c_first + ch + 1, cur ^ 1);
+            if (ch + 1 < nchunks && !(W4ABL & 1)) issue(c_first + ch + 1, cur ^ 1);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -550,10 +556,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (!(W4ABL & 4)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ch + 1 < nchunks) place_halo(cur ^ 1);
         __syncthreads();
+        }
     }
+    if ((W4ABL & 8) && prm.P > 0) return;
 
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + 16-byte stores: lane holds rows 4g..4g+3 of quad column r16
     const bool stats = prm.stat_sum != nullptr;
