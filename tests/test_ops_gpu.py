@@ -924,11 +924,13 @@ S2_DGRAD_CASES = [
     ("s5_like", 4, 128, 460, (8, 28, 28), "hw"),
     ("s8_full_size_k_parts", 22, 256, 921, (4, 14, 14), "hw"),
     ("ragged_rows_and_k", 3, 70, 37, (3, 10, 12), "hw"),
+    ("ragged_16_byte_pieces", 3, 70, 37, (2, 12, 16), "hw"),
     ("long_rows", 2, 16, 24, (2, 6, 254), "hw"),
     ("one_clip_one_frame", 1, 16, 8, (1, 2, 2), "hw"),
     ("t2_like", 3, 230, 128, (16, 28, 28), "t"),
     ("t8_full_size_k_parts", 22, 921, 512, (4, 7, 7), "t"),
     ("temporal_ragged", 3, 50, 19, (6, 5, 7), "t"),
+    ("temporal_ragged_16_byte_pieces", 3, 50, 19, (4, 6, 6), "t"),
     ("temporal_two_frames", 2, 16, 16, (2, 3, 3), "t"),
 ]
 
@@ -970,6 +972,9 @@ def test_conv3d_stride2_dgrad_all_classes_in_one_launch(case, monkeypatch):
             close(run(), ref, what=f"{name}: tile width {bn}, {ks} K parts")
     monkeypatch.delenv("ZSV_DGRAD_S2_BN")
     monkeypatch.delenv("ZSV_DGRAD_S2_KS")
+    monkeypatch.setenv("ZSV_DGRAD_S2_NO_X4", "1")             # 4-byte image DMAs (what clips of S % 4 != 0 voxels use)
+    assert torch.equal(run(), merged), "the DMA width does not change the arithmetic"
+    monkeypatch.delenv("ZSV_DGRAD_S2_NO_X4")
     monkeypatch.setenv("ZSV_NO_DGRAD_S2", "1")
     per_class = run()
     close(merged, per_class.double(), rtol=5e-6, what=f"{name}: merged vs class-by-class launches")

@@ -36,7 +36,8 @@ struct DgradS2Params {
     int P;                   // columns: dy voxels N * To * Ho * Wo
     int S, HW, Wc, Hc, Tc;   // dy: voxels per clip, per frame, row length, rows, frames
     int oS, oHW, oW;         // dx: voxels per clip, per frame, row length
-    int nseg;                // 64-float DMA segments of one image row
+    int nseg;                // 64-float DMA segments of one image row (4-byte form)
+    int nimg;                // floats of one image row that are read
     unsigned dy_bytes;
     int ksplit, chunks_per_split, slab_elems;
 };
@@ -60,17 +61,18 @@ __global__ __launch_bounds__(256) void dgrad_s2_pack_kernel(const float* __restr
     }
 }
 
-template <int BN, int KIND>
+// X4: dy clips are whole 16-byte pieces (S % 4 == 0; temporal form: frames too): one 16-byte DMA instruction per image row
+template <int BN, int KIND, bool X4>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm, const float* __restrict__ Wp,
                                                                const float* __restrict__ DY, float* __restrict__ DX) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 64, BK = 8, TM = 2, TN = BN / 32;
     constexpr int NTAP = S2Kind<KIND>::NTAP, NCLS = S2Kind<KIND>::NCLS, NSH = S2Kind<KIND>::NSH;
-    constexpr int MAXSEG = KIND == KIND_T ? 2 * BN / 64 : (BN == 128 ? 4 : 3);
-    constexpr int LBP = 64 * MAXSEG + 16;                  // = 16 mod 32: the two k rows of a 32-lane read group split the banks
+    constexpr int MAXSEG = X4 ? 1 : (KIND == KIND_T ? 2 * BN / 64 : (BN == 128 ? 4 : 3));
+    constexpr int LBP = X4 ? 272 : 64 * MAXSEG + 16;       // = 16 mod 32: the two k rows of a 32-lane read group split the banks
     constexpr int A_FLOATS = NTAP * BK * BM, B_FLOATS = BK * LBP, STAGE = A_FLOATS + B_FLOATS;
     constexpr int APIECES = NTAP * BK * BM / 256;          // 1-KiB pieces of the weight panel (4 k rows x 64 m)
-    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr unsigned OOB = X4 ? 0xFFFFFFF0u : 0xFFFFFFFFu;
     extern __shared__ __attribute__((aligned(16))) float pool[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,10 +91,10 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
     unsigned ibase[MAXSEG];
 #pragma unroll
     for (int s = 0; s < MAXSEG; ++s) {
-        const int e = 64 * s + lane;
+        const int e = X4 ? 4 * lane : 64 * s + lane;
         const int q = KIND == KIND_T ? n0 + e % BN : n0 + e;
         ibase[s] = OOB;
-        if (q < prm.P) {
+        if (q < prm.P && (!X4 || e < prm.nimg)) {
             const int n = q / prm.S;
             ibase[s] = 4u * (unsigned)(n * prm.Cout * prm.S + (q - n * prm.S) + (KIND == KIND_T ? (e / BN) * prm.HW : 0));
         }
@@ -110,10 +112,11 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
             const int k = wave + 4 * h;
             const int co = chunk * BK + k;
 #pragma unroll
-            for (int s = 0; s < MAXSEG; ++s)
-                if (s < prm.nseg)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LBP + 64 * s), 4,
-                                                             (int)(co < prm.Cout ? ibase[s] : OOB), co < prm.Cout ? co * ch_bytes : 0, 0, 0);
+            for (int s = 0; s < MAXSEG; ++s) {
+                const int voff = (int)(co < prm.Cout ? ibase[s] : OOB), soff = co < prm.Cout ? co * ch_bytes : 0;
+                if constexpr (X4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LBP), 16, voff, soff, 0, 0);
+                else if (s < prm.nseg) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LBP + 64 * s), 4, voff, soff, 0, 0);
+            }
         }
         const float* src = a_lane + (size_t)chunk * (NTAP * BK) * prm.Mp;
 #pragma unroll
@@ -303,16 +306,20 @@ size_t dgrad_s2_workspace_bytes(const zsv_conv_desc* d) {
     return s2_panel_bytes(d, pl) + (pl.ks > 1 ? (size_t)pl.ks * out_bytes : 0);
 }
 
-template <int BN, int KIND>
+template <int BN, int KIND, bool X4>
 static int s2_launch(const DgradS2Params& p, const float* wp, const float* dy, float* out, hipStream_t stream) {
     constexpr int NTAP = S2Kind<KIND>::NTAP;
     constexpr int MAXSEG = KIND == KIND_T ? 2 * BN / 64 : (BN == 128 ? 4 : 3);
-    constexpr int LDS_BYTES = 2 * (NTAP * 8 * 64 + 8 * (64 * MAXSEG + 16)) * 4;          // as in the kernel
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<BN, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    constexpr int LDS_BYTES = 2 * (NTAP * 8 * 64 + 8 * (X4 ? 272 : 64 * MAXSEG + 16)) * 4;          // as in the kernel
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_dgrad_s2_kernel<BN, KIND, X4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long blocks = (long)p.tiles_m * ((p.P + BN - 1) / BN) * p.ksplit;
-    hipLaunchKernelGGL((conv_dgrad_s2_kernel<BN, KIND>), dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, p, wp, dy, out);
+    hipLaunchKernelGGL((conv_dgrad_s2_kernel<BN, KIND, X4>), dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, p, wp, dy, out);
     return launch_status();
+}
+template <int BN, int KIND>
+static int s2_launch_x(bool x4, const DgradS2Params& p, const float* wp, const float* dy, float* out, hipStream_t stream) {
+    return x4 ? s2_launch<BN, KIND, true>(p, wp, dy, out, stream) : s2_launch<BN, KIND, false>(p, wp, dy, out, stream);
 }
 
 int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
@@ -328,7 +335,10 @@ int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
     p.S = d->To * d->Ho * d->Wo; p.HW = d->Ho * d->Wo; p.Wc = d->Wo; p.Hc = d->Ho; p.Tc = d->To;
     p.P = d->N * p.S;
     p.oS = d->Ti * d->Hi * d->Wi; p.oHW = d->Hi * d->Wi; p.oW = d->Wi;
-    p.nseg = pl.kind == KIND_T ? 2 * pl.bn / 64 : (pl.bn + d->Wo + 1 + 63) / 64;
+    p.nimg = pl.kind == KIND_T ? 2 * pl.bn : pl.bn + d->Wo + 1;
+    p.nseg = (p.nimg + 63) / 64;
+    const bool x4 = p.S % 4 == 0 && (pl.kind == KIND_HW || p.HW % 4 == 0) && p.nimg <= 256 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                    getenv("ZSV_DGRAD_S2_NO_X4") == nullptr;
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
     p.ksplit = pl.ks; p.chunks_per_split = pl.cps;
     p.slab_elems = (int)((long)d->N * d->Cin * p.oS);
@@ -341,8 +351,8 @@ int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     float* out = pl.ks > 1 ? slabs : dx;
     int st;
-    if (pl.kind == KIND_HW) st = pl.bn == 128 ? s2_launch<128, KIND_HW>(p, wp, dy, out, stream) : s2_launch<64, KIND_HW>(p, wp, dy, out, stream);
-    else st = pl.bn == 128 ? s2_launch<128, KIND_T>(p, wp, dy, out, stream) : s2_launch<64, KIND_T>(p, wp, dy, out, stream);
+    if (pl.kind == KIND_HW) st = pl.bn == 128 ? s2_launch_x<128, KIND_HW>(x4, p, wp, dy, out, stream) : s2_launch_x<64, KIND_HW>(x4, p, wp, dy, out, stream);
+    else st = pl.bn == 128 ? s2_launch_x<128, KIND_T>(x4, p, wp, dy, out, stream) : s2_launch_x<64, KIND_T>(x4, p, wp, dy, out, stream);
     if (st || pl.ks == 1) return st;
     return splitk_reduce(slabs, pl.ks, p.slab_elems, d->Cin, p.oS, nullptr, 0, dx, stream);
 }
