@@ -339,6 +339,7 @@ static long tap_ksplit_for(long tiles, long nchunks) {
     // 1024 workgroups are resident at once (256 CUs x 4); split K when one round is under-filled
     long thresh = 700, target = 1024;
     if (getenv("ZSV_NO_SPLITK")) return 1;
+    if (const char* e = getenv("ZSV_TAP_KS")) return atol(e) < 1 ? 1 : (atol(e) > nchunks ? nchunks : atol(e));      // (sweeps)
     if (const char* e = getenv("ZSV_SPLITK_THRESH")) thresh = atol(e);
     if (tiles >= thresh || nchunks < 32) return 1;
     long ks = (target + tiles / 2) / tiles;              // nearest whole multiple of the tile count
