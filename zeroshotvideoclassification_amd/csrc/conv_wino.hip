@@ -395,7 +395,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 16 * TM, BN = 256, BK = 16, NP = 6;
     constexpr bool USINGLE = TM >= 4;
-    constexpr int LDB = 264, C0 = 4;           // image row: left halo at column 3, the 256 voxels at 4..259, right halo at 260
+    constexpr int LDB = 272, C0 = 4;           // image row: left halo at column 3, the 256 voxels at 4..259, right halo at 260; 4 * LDB = 0 mod 64:
+                                               // the k rows 4g+s of the lane groups of a ds_read_b128 keep their own 16-byte slots (pitch 264: 2-way conflicts)
     constexpr int A_FLOATS = NP * BM * BK, B_FLOATS = BK * LDB;
     constexpr int IMG = B_FLOATS + 64;         // image + 64 floats of scratch where the halo DMA lands
     constexpr int STAGE = A_FLOATS + IMG;
@@ -518,14 +519,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
         }
-        float dl[2], dr[2];
+        // d1..d4: one ds_read_b128; d0 / d5 are the neighbouring lanes' d4 / d1 (DPP row shifts inside the 16-lane row of a
+        // k group) except at the two ends of the wave's 64 voxels, which lanes 0 / 15 of a row read from LDS (`de`): one
+        // 4-byte read per k step instead of two 4-way bank-conflicted ones
+        float de[2];
         f32x4 dm[2];
         auto fetch = [&](int s, int slot) {
             if ((W4ABL & 2) && ch > 0) return;
             const float* src = bs + (4 * g + s) * LDB + C0 + 64 * wave + 4 * r16;        // image column of d1
-            dl[slot] = src[-1];
             dm[slot] = *reinterpret_cast<const f32x4*>(src);
-            dr[slot] = src[4];
+            de[slot] = src[r16 == 0 ? -1 : 4];           // (used by lanes 0 and 15 of a row only)
         };
         fetch(0, 0);
         if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
@@ -535,8 +538,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int sl = s & 1;
-            const float d0 = zero_d0 ? 0.f : dl[sl], d1 = dm[sl][0], d2 = dm[sl][1], d3 = dm[sl][2], d4 = dm[sl][3],
-                        d5 = zero_d5 ? 0.f : dr[sl];
+            const float d1 = dm[sl][0], d2 = dm[sl][1], d3 = dm[sl][2], d4 = dm[sl][3];
+            const float dl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(de[sl]), __float_as_int(d4), 0x111, 0xf, 0xf, false));   // row_shr:1
+            const float dr = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(de[sl]), __float_as_int(d1), 0x101, 0xf, 0xf, false));   // row_shl:1
+            const float d0 = zero_d0 ? 0.f : dl, d5 = zero_d5 ? 0.f : dr;
             float v[NP];
             const float t12 = d1 + d2, t34 = d3 + d4, u12 = d1 - d2, u43 = d4 - d3, u42 = d4 - d2, u31 = d3 - d1;
             v[0] = __fmaf_rn(4.f, d0, __fmaf_rn(-5.f, d2, d4));
@@ -939,11 +944,17 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
 
 template <int TM, int NCHUNKS>
 static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
-    constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 264 + 64;                           // as in the kernel
+    constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 272 + 64;                           // as in the kernel
     constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
+    if (const char* e = getenv("ZSV_WINO_LDS_PAD")) {        // occupancy experiment: a bigger allocation = one workgroup per CU
+        const int bytes = LDS_BYTES + atoi(e);
+        if (hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
+        hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), bytes, stream, p, up, in, out);
+        return launch_status();
+    }
     hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
