@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         }
 #pragma unroll
         for (int j = 0; j < APASS; ++j) {
-            const int piece = wave + 4 * j;
+            const int piece = (3 - wave) + 4 * j;        // (wave 0 also carries the halo DMA: it gets the short share when the pieces do not divide)
             if (piece < NPIECES) {
                 const int pt = piece / TM, ib = piece % TM;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_ptr_t)(us + 256 * piece), 16, u_lane_bytes,
