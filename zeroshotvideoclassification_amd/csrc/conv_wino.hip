@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (!USINGLE && ch + 1 < nchunks && !(W4ABL & 1)) issue(c_first + ch + 1, cur ^ 1);
+        const bool prefetching = ch + 1 < nchunks && !(W4ABL & 1);
         const float* as = u_of(cur);
         const float* bs = img_of(cur);
         f32x4 a4[NP][TM];
@@ -533,7 +533,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         fetch(0, 0);
         if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
             __syncthreads();
-            if (ch + 1 < nchunks && !(W4ABL & 1)) issue(c_first + ch + 1, cur ^ 1);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -560,6 +559,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
                     acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            // the next chunk's DMAs go out after the first burst, not at the head of the chunk next to its 18 + 2 LDS reads (and, at 64 rows, after the
+            // barrier that frees the single U panel); spreading them over the later gaps leaves the last ones too little time to land (measured)
+            if (s == 0 && prefetching) issue(c_first + ch + 1, cur ^ 1);
         }
         if (!(W4ABL & 4)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
