@@ -88,6 +88,16 @@ int zsv_conv3d_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, fl
 int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d);
 int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv3d_input_grad(dy, w) + the gradient of the block's strided 1x1x1 shortcut convolution, which reads the same input
+ * (`downsample`, resnet.py:240-246, next to the strided first convolution of the block, resnet.py:40-45).  `sub` is that gradient
+ * in COMPACT form [N][Cin][ceil(Ti/st)][Hi/sh][Wi/sw] -- the input gradient of the 1x1x1 convolution taken at stride 1 over its
+ * own output voxels -- and is added where dx[.., st*a, sh*b, sw*c] is produced: no zero-filled full-size tensor, no separate add
+ * over the block input (aten's autograd: two full-size gradients summed).  Only where
+ * zsv_conv3d_dgrad_add_strided_supported(d, st, sh, sw) != 0 (the merged stride-(1,2,2) kernel; st = 1 or 2, sh = sw = 2);
+ * workspace as zsv_conv3d_dgrad. */
+int32_t zsv_conv3d_dgrad_add_strided_supported(const zsv_conv_desc* d, int32_t st, int32_t sh, int32_t sw);
+int zsv_conv3d_dgrad_add_strided(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int32_t st, int32_t sh,
+                                 int32_t sw, float* dx, void* workspace, size_t workspace_bytes, void* stream);
 /* dw = conv3d_weight_grad(x, dy).  Deterministic: position range is cut into a fixed
  * number of slices, each slice writes a partial slab into `workspace`, a second kernel
  * sums the slabs in slice order. */

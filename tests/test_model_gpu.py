@@ -406,6 +406,72 @@ def test_identity_shortcut_gradient_is_added_in_the_dgrad_epilogue(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("inplanes,planes,shape", [(64, 128, (3, 64, 8, 56, 56)), (256, 512, (3, 256, 4, 14, 14)), (64, 128, (2, 64, 6, 20, 28))],
+                         ids=["layer2_like", "layer4_like_k_parts", "t_not_a_multiple_of_four"])
+def test_strided_shortcut_gradient_is_added_in_the_dgrad_epilogue(inplanes, planes, shape, monkeypatch):
+    """BasicBlock with a strided 1x1x1 `downsample` (resnet.py:240-246): the linked path (ops.DownLink: the shortcut's input
+    gradient in compact form, added inside the strided first convolution's dgrad) against the unlinked path (zero-filled
+    full-size shortcut gradient + autograd's add): same forward, same parameter gradients bit for bit; the input gradient to
+    rounding (the compact shortcut gradient is a stride-1 problem with its own tiling, and with K parts the add joins part 0)."""
+    from zeroshotvideoclassification_amd import layers, ops, resnet
+    torch.manual_seed(5)
+    down = torch.nn.Sequential(layers.Conv3d(inplanes, planes, kernel_size=1, stride=(2, 2, 2), bias=False), layers.BatchNorm3d(planes))
+    block = resnet.BasicBlock(inplanes, planes, resnet.Conv2Plus1D, stride=2, downsample=down).to(DEV).train()
+    x0 = torch.randn(shape, device=DEV)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        links = []
+        orig = ops.DownLink.__init__
+
+        def spy(self, strides):
+            orig(self, strides)
+            links.append(self)
+        monkeypatch.setattr(ops.DownLink, "__init__", spy)
+        y = block(x)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        y.backward(torch.randn(y.shape, generator=g).to(DEV))
+        monkeypatch.setattr(ops.DownLink, "__init__", orig)
+        return y.detach(), x.grad, [p.grad.clone() for p in block.parameters()], links
+
+    y1, g1, p1, links = run()
+    assert len(links) == 1 and links[0].armed and links[0].consumed and links[0].dsub is None      # parked, then collected
+    block.zero_grad()
+    monkeypatch.setenv("ZSV_NO_DOWN_FUSION", "1")
+    y2, g2, p2, links2 = run()
+    assert links2 == []
+    assert torch.equal(y1, y2)
+    for a, b in zip(p1, p2):
+        assert torch.equal(a, b)
+    err = (g1 - g2).abs().max().item()
+    assert err <= 2e-6 * g2.abs().max().item(), (err, g2.abs().max().item())
+    # the fused input gradient against torch CPU fp64 on the same block
+    xr = x0.double().cpu().requires_grad_(True)
+    blk = block.cpu().double()
+    try:
+        import torch.nn.functional as F
+        c1s, bn_mid, _, c1t = list(blk.conv1[0])
+        bn1 = blk.conv1[1]
+        c2s, bn_mid2, _, c2t = list(blk.conv2[0])
+        bn2 = blk.conv2[1]
+        dconv, dbn = list(blk.downsample)
+
+        def bn(m, t):
+            return F.batch_norm(t, None, None, m.weight, m.bias, True, 0.0, m.eps)
+        h = F.relu(bn(bn_mid, F.conv3d(xr, c1s.weight, None, c1s.stride, c1s.padding)))
+        h = F.relu(bn(bn1, F.conv3d(h, c1t.weight, None, c1t.stride, c1t.padding)))
+        h = F.relu(bn(bn_mid2, F.conv3d(h, c2s.weight, None, c2s.stride, c2s.padding)))
+        h = bn(bn2, F.conv3d(h, c2t.weight, None, c2t.stride, c2t.padding))
+        yr = F.relu(h + bn(dbn, F.conv3d(xr, dconv.weight, None, dconv.stride, dconv.padding)))
+        g = torch.Generator(device="cpu").manual_seed(9)
+        yr.backward(torch.randn(yr.shape, generator=g).double())
+        # (relative L2: a ReLU input within rounding of zero flips its mask and moves single voxels by O(0.1))
+        e64 = ((g1.double().cpu() - xr.grad).norm() / xr.grad.norm()).item()
+        assert e64 <= 2e-3, e64
+    finally:
+        block.float().to(DEV)
+
+
 @pytest.mark.parametrize("n,t,h,w", [(2, 8, 72, 88), (3, 10, 50, 50)])
 def test_odd_clip_sizes_forward_backward_match_the_oracle(n, t, h, w):
     """Clip sizes whose feature maps are odd / not multiples of the kernels' vector widths (voxel counts

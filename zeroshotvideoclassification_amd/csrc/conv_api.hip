@@ -270,7 +270,7 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
     if (!dy || !w || !dx) return ZSV_E_NULL;
     if (add != nullptr && !zsv_conv3d_dgrad_add_supported(d)) return ZSV_E_UNSUPPORTED;
     if (wino_dgrad_applicable(d)) return wino_dgrad(d, dy, w, add, dx, workspace, workspace_bytes, (hipStream_t)stream);
-    if (dgrad_s2_applicable(d)) return dgrad_s2(d, dy, w, dx, workspace, workspace_bytes, (hipStream_t)stream);     // (stride 2: no `add`)
+    if (dgrad_s2_applicable(d)) return dgrad_s2(d, dy, w, nullptr, 1, dx, workspace, workspace_bytes, (hipStream_t)stream);     // (stride 2: no `add`)
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -306,6 +306,23 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
             }
     if (ks > 1) return splitk_reduce(slabs, ks, out_elems, d->Cin, p.oS, nullptr, 0, dx, (hipStream_t)stream);
     return ZSV_OK;
+}
+
+// ---- dx = dgrad + the gradient of the block's strided 1x1x1 shortcut convolution (resnet.py:240-246: `downsample`), which reads the
+// same input: `sub` is that gradient in compact form [N][Cin][ceil(Ti/st)][Hi/sh][Wi/sw] (its non-zero voxels only), added where
+// dx[.., st*a, sh*b, sw*c] is produced -- no zero-filled full-size tensor, no separate add pass over the block input
+extern "C" int32_t zsv_conv3d_dgrad_add_strided_supported(const zsv_conv_desc* d, int32_t st, int32_t sh, int32_t sw) {
+    if (conv_check(d) != ZSV_OK || wino_dgrad_applicable(d)) return 0;
+    return dgrad_s2_sub_supported(d, st, sh, sw) ? 1 : 0;
+}
+
+extern "C" int zsv_conv3d_dgrad_add_strided(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int32_t st,
+                                            int32_t sh, int32_t sw, float* dx, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = conv_check(d);
+    if (rc) return rc;
+    if (!dy || !w || !dx || !sub) return ZSV_E_NULL;
+    if (!zsv_conv3d_dgrad_add_strided_supported(d, st, sh, sw)) return ZSV_E_UNSUPPORTED;
+    return dgrad_s2(d, dy, w, sub, st, dx, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" size_t zsv_linear_fwd_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {

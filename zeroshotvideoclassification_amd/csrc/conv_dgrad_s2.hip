@@ -40,6 +40,10 @@ struct DgradS2Params {
     int nimg;                // floats of one image row that are read
     unsigned dy_bytes;
     int ksplit, chunks_per_split, slab_elems;
+    // != nullptr (spatial form): the gradient of a strided 1x1x1 shortcut convolution of the same input, [N][M][subT][Hc][Wc]
+    // (its voxels are the class-(0,0) voxels of every sub_st-th frame), added in the epilogue: dx[.., sub_st*a, 2b, 2c] += sub[.., a, b, c]
+    const float* sub;
+    int sub_st, subT;
 };
 
 enum { KIND_HW = 0, KIND_T = 1 };
@@ -225,6 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
         float* base = DX + (size_t)n * prm.M * prm.oS;
         if constexpr (KIND == KIND_HW) base += t * prm.oHW + 2 * hh * prm.oW + 2 * ww;
         else base += 2 * t * prm.oHW + r;
+        // shortcut gradient (spatial form; with K parts: added by part 0 only)
+        const float* sub = nullptr;
+        int sub_pitch = 0;
+        if constexpr (KIND == KIND_HW) {
+            if (prm.sub != nullptr && split == 0 && t % prm.sub_st == 0) {
+                sub_pitch = prm.subT * prm.HW;
+                sub = prm.sub + (size_t)n * prm.M * sub_pitch + (t / prm.sub_st) * prm.HW + r;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_s2_kernel(DgradS2Params prm
                 if (m >= prm.M) continue;
                 float* o = base + (size_t)m * prm.oS;
                 if constexpr (KIND == KIND_HW) {
+                    if (sub != nullptr) acc[0][i][j][r4] += sub[(size_t)m * sub_pitch];
                     *reinterpret_cast<float2*>(o) = float2{acc[0][i][j][r4], acc[1][i][j][r4]};
                     *reinterpret_cast<float2*>(o + prm.oW) = float2{acc[2][i][j][r4], acc[3][i][j][r4]};
                 } else {
@@ -322,10 +336,17 @@ static int s2_launch_x(bool x4, const DgradS2Params& p, const float* wp, const f
     return x4 ? s2_launch<BN, KIND, true>(p, wp, dy, out, stream) : s2_launch<BN, KIND, false>(p, wp, dy, out, stream);
 }
 
-int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
-             hipStream_t stream) {
+// dx += zero-insertion of `sub` (the gradient of a 1x1x1 convolution of stride (sub_st, 2, 2) on the same input) -- spatial form only
+bool dgrad_s2_sub_supported(const zsv_conv_desc* d, int st, int sh, int sw) {
+    S2Plan pl;
+    return s2_plan(d, pl) && pl.kind == KIND_HW && sh == 2 && sw == 2 && (st == 1 || st == 2) && getenv("ZSV_NO_DOWN_FUSION") == nullptr;
+}
+
+int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int sub_st, float* dx, void* workspace,
+             size_t workspace_bytes, hipStream_t stream) {
     S2Plan pl;
     if (!s2_plan(d, pl)) return ZSV_E_UNSUPPORTED;
+    if (sub != nullptr && !dgrad_s2_sub_supported(d, sub_st, 2, 2)) return ZSV_E_UNSUPPORTED;
     if (!workspace || workspace_bytes < dgrad_s2_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(dx) & 7) != 0) return ZSV_E_UNSUPPORTED;
     const int ntap = pl.kind == KIND_HW ? 9 : 3;
@@ -342,6 +363,7 @@ int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx,
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
     p.ksplit = pl.ks; p.chunks_per_split = pl.cps;
     p.slab_elems = (int)((long)d->N * d->Cin * p.oS);
+    p.sub = sub; p.sub_st = sub ? sub_st : 1; p.subT = sub ? (d->Ti + sub_st - 1) / sub_st : 0;
     float* wp = (float*)workspace;
     float* slabs = (float*)((char*)workspace + s2_panel_bytes(d, pl));
     const long total = (long)pl.nchunks * ntap * 8 * p.Mp;

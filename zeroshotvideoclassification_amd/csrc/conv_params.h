@@ -193,8 +193,9 @@ int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const fl
 // every residue class of a stride-2 dgrad in one launch (conv_dgrad_s2.hip): 1x3x3 stride (1,2,2) and 3x1x1 stride (2,1,1)
 bool dgrad_s2_applicable(const zsv_conv_desc* d);
 size_t dgrad_s2_workspace_bytes(const zsv_conv_desc* d);
-int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
-             hipStream_t stream);
+bool dgrad_s2_sub_supported(const zsv_conv_desc* d, int st, int sh, int sw);
+int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int sub_st, float* dx, void* workspace,
+             size_t workspace_bytes, hipStream_t stream);
 bool wino_fwd_applicable(const zsv_conv_desc* d);
 bool wino_fwd_pre_capable(const zsv_conv_desc* d);   // the temporal F(2,3)-along-T forward: can apply a BatchNorm + ReLU prologue
 int wino_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* w, float* stat_sum,

@@ -183,13 +183,29 @@ class SkipLink:
         self.armed = False        # set by the convolution's forward: its backward will collect `dres`
 
 
+class DownLink:
+    """Joins the two gradient paths of a block with a strided 1x1x1 shortcut convolution (`downsample`, resnet.py:240-246): the
+    block input feeds the strided first convolution AND the shortcut convolution.  The shortcut's backward runs first (it was
+    recorded later) and parks its input gradient here in COMPACT form -- only the voxels it reads -- instead of returning a
+    zero-filled full-size tensor; the backward of the block's first convolution adds it in its dgrad epilogue
+    (zsv_conv3d_dgrad_add_strided).  If the order ever differs (`consumed` already set) the shortcut returns its gradient the
+    ordinary way."""
+    __slots__ = ("strides", "dsub", "armed", "consumed")
+
+    def __init__(self, strides):
+        self.strides = tuple(int(v) for v in strides)
+        self.dsub = None
+        self.armed = False        # set by the first convolution's forward: its backward will collect `dsub`
+        self.consumed = False
+
+
 # ------------------------------------------------------------------------------------------
 class _Conv3d(Function):
     """aten::conv3d fwd / dgrad / wgrad (resnet.py:23-30,40-52,63-70,170,181,184,270;
     network.py:102-117), optional bias and fused ReLU (network.py:147-162)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, skip_link=None):
+    def forward(ctx, x, weight, bias, stride, padding, relu, want_stats, skip_link=None, down_link=None, down_src=None):
         _require(x, weight, bias)
         ctx.set_materialize_grads(False)      # no zero tensor for the (non-differentiable) statistics output
         if x.dim() != 5 or weight.dim() != 5:
@@ -223,6 +239,14 @@ class _Conv3d(Function):
         if skip_link is not None and lib.zsv_conv3d_dgrad_add_supported(byref(d)):
             ctx.skip_link = skip_link
             skip_link.armed = True
+        ctx.down_link = None          # this convolution collects the strided shortcut's gradient in its dgrad
+        if down_link is not None and lib.zsv_conv3d_dgrad_add_strided_supported(byref(d), *down_link.strides):
+            ctx.down_link = down_link
+            down_link.armed = True
+        ctx.down_src = None           # this convolution IS the strided 1x1x1 shortcut: park the compact gradient
+        if down_src is not None and down_src.armed and (d.kT, d.kH, d.kW) == (1, 1, 1) and (d.pT, d.pH, d.pW) == (0, 0, 0) \
+                and (d.sT, d.sH, d.sW) == down_src.strides:
+            ctx.down_src = down_src
         ctx.save_for_backward(x, weight, y if relu else None)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -235,7 +259,7 @@ class _Conv3d(Function):
         d = ctx.desc
         lib = _lib.load()
         if dy is None:                          # output unused downstream
-            return None, None, None, None, None, None, None, None
+            return (None,) * 10
         dy = dy.contiguous()
         dx = dw = db = None
         with torch.cuda.device(dy.device):
@@ -253,15 +277,35 @@ class _Conv3d(Function):
                 else:
                     _lib.check(lib.zsv_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), g.numel(), _stream()), "zsv_relu_bwd")
                 dy = g
-            if ctx.needs_input_grad[0]:
+            src = ctx.down_src
+            if ctx.needs_input_grad[0] and src is not None and not src.consumed:
+                # strided 1x1x1 shortcut: its input gradient over its own output voxels only (a stride-1 problem on the compact
+                # grid), parked for the block's first convolution; this node contributes no full-size gradient
+                d1 = conv_desc((d.N, d.Cin, d.To, d.Ho, d.Wo), weight.shape, (1, 1, 1), (0, 0, 0))
+                dsub = torch.empty((d.N, d.Cin, d.To, d.Ho, d.Wo), dtype=torch.float32, device=dy.device)
+                nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d1))
+                ws = _workspace(nbytes, dy.device)
+                _lib.check(lib.zsv_conv3d_dgrad(byref(d1), dy.data_ptr(), weight.data_ptr(), dsub.data_ptr(), _ptr(ws), nbytes,
+                                                _stream()), "zsv_conv3d_dgrad (compact shortcut gradient)")
+                src.dsub = dsub
+            elif ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
                 ws = _workspace(nbytes, dy.device)
                 add = None
                 if ctx.skip_link is not None:            # the shortcut's gradient, parked by the block's tail
                     add, ctx.skip_link.dres = ctx.skip_link.dres, None
-                _lib.check(lib.zsv_conv3d_dgrad_add(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
-                                                    _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
+                link = ctx.down_link
+                if link is not None:
+                    link.consumed = True
+                if link is not None and link.dsub is not None:      # the strided shortcut's compact gradient
+                    sub, link.dsub = link.dsub, None
+                    _lib.check(lib.zsv_conv3d_dgrad_add_strided(byref(d), dy.data_ptr(), weight.data_ptr(), sub.data_ptr(),
+                                                                link.strides[0], link.strides[1], link.strides[2], dx.data_ptr(),
+                                                                _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad_add_strided")
+                else:
+                    _lib.check(lib.zsv_conv3d_dgrad_add(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
+                                                        _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
             if ctx.needs_input_grad[1]:
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
 
@@ -275,7 +319,7 @@ class _Conv3d(Function):
                 dw = _on_wgrad_stream(launch, (x, dy), weight)
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = channel_sum(dy)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False, want_stats=False):
@@ -284,9 +328,11 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False, want_stats=Fal
     ``BasicBlock.forward``: the tensor is also the block's identity shortcut) makes this convolution's
     backward add the shortcut gradient in its dgrad epilogue."""
     link = x.__dict__.pop("_zsv_skip_link", None) if hasattr(x, "__dict__") else None
-    if link is not None and not (torch.is_grad_enabled() and x.requires_grad):
-        link = None
-    y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats), link)
+    down = x.__dict__.pop("_zsv_down_link", None) if hasattr(x, "__dict__") else None        # (``DownLink``: consumer / producer tags)
+    src = x.__dict__.pop("_zsv_down_src", None) if hasattr(x, "__dict__") else None
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        link = down = src = None
+    y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats), link, down, src)
     return (y, stats) if want_stats else y
 
 

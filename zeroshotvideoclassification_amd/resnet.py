@@ -152,11 +152,25 @@ class BasicBlock(nn.Module):
                 and os.environ.get("ZSV_NO_SKIP_FUSION") is None:
             link = ops.SkipLink()
             x._zsv_skip_link = link
+        # strided 1x1x1 shortcut convolution: x feeds conv1's first (strided) convolution AND `downsample`; link the two so that
+        # the shortcut's input gradient is added inside that convolution's dgrad in compact form (ops.DownLink)
+        down = None
+        ds_conv = self.downsample[0] if isinstance(self.downsample, nn.Sequential) and len(self.downsample) > 0 else None
+        if isinstance(ds_conv, Conv3d) and tuple(ds_conv.kernel_size) == (1, 1, 1) and torch.is_grad_enabled() and x.requires_grad \
+                and os.environ.get("ZSV_NO_DOWN_FUSION") is None:
+            down = ops.DownLink(ds_conv.stride)
+            x._zsv_down_link = down
         out = self.conv1(x)
         if link is not None:
             x.__dict__.pop("_zsv_skip_link", None)           # (not consumed: conv1 does not start with a Conv3d)
+        if down is not None:
+            x.__dict__.pop("_zsv_down_link", None)
         out, stats = _call(self.conv2[0], out, fused_tail and tail.training)
+        if down is not None and down.armed:
+            x._zsv_down_src = down
         residual = x if self.downsample is None else self.downsample(x)
+        if down is not None:
+            x.__dict__.pop("_zsv_down_src", None)
         if fused_tail:
             # BN + `out += residual` + ReLU (resnet.py:97,110-111) in one pass
             return tail(out, residual=residual, relu=True, stats=stats, skip_link=link)
