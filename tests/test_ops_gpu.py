@@ -844,9 +844,10 @@ def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, 
                          ids=["t1_like", "layer2_ragged_last_segment", "three_row_tiles", "ragged_rows_45", "layer3_t4_partial_tiles",
                               "ragged_k_20_channels"])
 def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
-    """Temporal 3x1x1 stride-1 convolutions through the F(2,3)-along-T kernel (conv_winot_kernel): forward (plain, with the
-    BatchNorm partial statistics) and input gradient (plain, with the fused shortcut add) against torch CPU fp64 and against
-    the direct kernel; the folded BatchNorm + ReLU prologue bit-identical to the separate pass."""
+    """Temporal 3x1x1 stride-1 convolutions through the Winograd-along-T kernels (conv_winot4_kernel, F(4,3), and conv_winot_kernel,
+    F(2,3)): forward (plain, with the BatchNorm partial statistics) and input gradient (plain, with the fused shortcut add) against
+    torch CPU fp64, against each other and against the direct kernel; the folded BatchNorm + ReLU prologue bit-identical to the
+    separate pass."""
     import ctypes
     from zeroshotvideoclassification_amd import _lib, layers
     t, h, w = thw
@@ -911,10 +912,24 @@ def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
             return out.detach(), xg.grad, conv.weight.grad, bn.weight.grad
         for a, b in zip(chain(True), chain(False)):
             assert torch.equal(a, b), "folded BatchNorm differs from the separate pass"
+    # F(4,3) (default) against F(2,3) along T, then both against the direct kernel (F(4,3): transform constants up to 8, tested at 1e-5)
+    monkeypatch.setenv("ZSV_WINOT_NO_F43", "1")
+    y23, stats23 = fwd(True)
+    dx23 = dgrad(False)
+    close(y23, yr, what="temporal F(2,3) fwd")
+    close(dx23, dxr, what="temporal F(2,3) dgrad")
+    close(stats23[0].double().sum(1), yr.sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="temporal F(2,3) fwd: sum y")
+    close(y, y23.double(), rtol=1e-5, what="temporal F(4,3) vs F(2,3) (fwd)")
+    close(dx, dx23.double(), rtol=1e-5, what="temporal F(4,3) vs F(2,3) (dgrad)")
+    assert not torch.equal(y, y23), "the two forms should not be the same kernel"
+    monkeypatch.delenv("ZSV_WINOT_NO_F43")
     monkeypatch.setenv("ZSV_NO_WINOT", "1")
     yd, _ = fwd(False)
-    close(y, yd.double(), rtol=5e-6, what="temporal winograd vs direct kernel (fwd)")
-    close(dx, dgrad(False).double(), rtol=5e-6, what="temporal winograd vs direct kernel (dgrad)")
+    dxd = dgrad(False)
+    close(y, yd.double(), rtol=1e-5, what="temporal winograd vs direct kernel (fwd)")
+    close(dx, dxd.double(), rtol=1e-5, what="temporal winograd vs direct kernel (dgrad)")
+    close(y23, yd.double(), rtol=5e-6, what="temporal F(2,3) vs direct kernel (fwd)")
+    close(dx23, dxd.double(), rtol=5e-6, what="temporal F(2,3) vs direct kernel (dgrad)")
     assert not torch.equal(y, yd), "the two paths should not be the same kernel (forward)"
 
 

@@ -842,6 +842,216 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
 #endif
 }
 
+// ================================================================================================
+// The same temporal convolution in F(4,3) form ALONG T (T % 4 == 0: every T the F(2,3) kernel takes): four frames t..t+3 of one
+// (h, w) position share the six input frames d0..d5 = in[t-1..t+4]; V, U and the output transform are conv_wino4_kernel's with T in
+// the place of W -- 6 multiplies per 4 outputs instead of 12: 25 % fewer MFMAs than conv_winot_kernel.  Tile and image as there (all
+// T frames of PW = 256 / T positions, [16 k][T][PW], no halo: frames -1 and T..T+3 are a wave-uniform zeroing of d0 / d5); 64 frame
+// QUADS per workgroup, one 16-quad block (16 positions of one quad) per wave, six accumulator sets.  At 64 rows the six U panels are
+// single-buffered (a second barrier per chunk, as conv_wino4_kernel) so that two workgroups fit a CU.
+template <int TM, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, const float* __restrict__ Up,
+                                                             const float* __restrict__ IN, float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 16 * TM, BK = 16, NP = 6;
+    constexpr bool USINGLE = TM >= 4;
+    constexpr int LDB = 260;                // 256 used; 4 * LDB = 16 mod 32: the k rows 4g+s of the two lane halves of a ds_read_b32 split the banks
+    constexpr int A_FLOATS = NP * BM * BK, B_FLOATS = BK * LDB;
+    constexpr int IMG = B_FLOATS + (PRE ? 256 : 0);     // image (+ PRE: 1 KiB DMA target, 32 floats used: 16 scales, 16 shifts)
+    constexpr int STAGE = A_FLOATS + IMG;
+    constexpr unsigned OOB16 = 0xFFFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) float pool[];
+    auto u_of = [&](int buf) -> float* { return pool + (USINGLE ? 0 : buf * STAGE); };
+    auto img_of = [&](int buf) -> float* { return pool + (USINGLE ? A_FLOATS + buf * IMG : buf * STAGE + A_FLOATS); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);          // the row tiles of one column tile are neighbours (one L2)
+    const int m0 = (tile % prm.tiles_m) * BM;
+    const int ct = tile / prm.tiles_m;                          // column tile = (clip, position segment)
+    const int n_img = ct / prm.segs, pos0 = (ct - n_img * prm.segs) * prm.PW;
+    const int T = prm.T, PW = prm.PW, HW = prm.HW;
+    const int pq = PW >> 2;                                     // 16-byte pieces per frame row
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
+    const int ch_bytes = 4 * prm.S;
+    // this lane's 16-byte piece of every k row: frame lane / pq, positions pos0 + 4 * (lane % pq) ..
+    const int pf = lane / pq, pp = pos0 + 4 * (lane - pf * pq);
+    const unsigned piece_off = pp < HW ? (unsigned)(4 * (n_img * prm.C * prm.S + pf * HW + pp)) : OOB16;
+
+    constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
+    const float* a_src[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int q = (3 - wave) + 4 * j, qq = q < NPIECES ? q : 0, pt = qq / TM, ib = qq % TM, row = lane >> 2;
+        const int sw = ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 4;
+        a_src[j] = Up + ((size_t)pt * prm.Mp + m0 + 16 * ib + row) * 16 + sw;
+    }
+    const size_t a_chunk_stride = (size_t)NP * BK * prm.Mp;
+    const __amdgpu_buffer_rsrc_t pre_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? prm.pre_coef : IN), 0, PRE ? 8u * (unsigned)prm.pre_pitch : 0u, 0x00020000);
+
+    const int nchunks = prm.nblk;
+    auto issue = [&](int chunk, int buf) {
+        float* as = u_of(buf);
+        float* bs = img_of(buf);
+        const int ci0 = chunk * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB), 16, (int)(ci < prm.C ? piece_off : OOB16),
+                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            const int q = (3 - wave) + 4 * j;
+            if (q < NPIECES)
+                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * q), 16, 0, 0);
+        }
+        if constexpr (PRE) {
+            if (wave == 0) {
+                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : OOB16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(bs + B_FLOATS), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[NP][TM];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, r16 = lane & 15;
+    // this wave's 16-quad block: block b = wave = (frame quad b / (PW/16), 16-position group b % (PW/16))
+    const int groups = PW >> 4;
+    const int tq = wave / groups;
+    const int col = 16 * (wave - tq * groups) + r16;               // position inside the tile
+    const bool zero_d0 = tq == 0;                                   // frame -1
+    const bool zero_d5 = 4 * tq + 4 >= T;                           // frame T
+    const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
+
+    issue(0, 0);
+    __syncthreads();                                   // (vmcnt(0) before the barrier)
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int cur = ch & 1;
+        if (!USINGLE && ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        const float* as = u_of(cur);
+        const float* bs = img_of(cur);
+        f32x4 a4[NP][TM];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
+        float psc[PRE ? 4 : 1], psh[PRE ? 4 : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                psc[s] = bs[B_FLOATS + 4 * g + s];
+                psh[s] = bs[B_FLOATS + 16 + 4 * g + s];
+            }
+        }
+        float raw[2][NP];
+        auto fetch = [&](int s, int slot) {
+            const float* row = bs + (4 * g + s) * LDB;
+            const int f0 = 4 * tq - 1;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int f = min(max(f0 + i, 0), T - 1);           // (clamped: the out-of-clip frames are zeroed below)
+                raw[slot][i] = row[f * PW + col];
+            }
+        };
+        fetch(0, 0);
+        if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
+            __syncthreads();
+            if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int sl = s & 1;
+            float d[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                d[i] = raw[sl][i];
+                if constexpr (PRE) d[i] = fmaxf(__fmaf_rn(d[i], psc[s], psh[s]), 0.f);
+            }
+            const float d0 = zero_d0 ? 0.f : d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = zero_d5 ? 0.f : d[5];
+            float v[NP];
+            const float t12 = d1 + d2, t34 = d3 + d4, u12 = d1 - d2, u43 = d4 - d3, u42 = d4 - d2, u31 = d3 - d1;
+            v[0] = __fmaf_rn(4.f, d0, __fmaf_rn(-5.f, d2, d4));
+            v[1] = __fmaf_rn(-4.f, t12, t34);
+            v[2] = __fmaf_rn(4.f, u12, u43);
+            v[3] = __fmaf_rn(2.f, u31, u42);
+            v[4] = __fmaf_rn(-2.f, u31, u42);
+            v[5] = __fmaf_rn(4.f, d1, __fmaf_rn(-5.f, d3, d5));
+            if (s < 3) fetch(s + 1, sl ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                               // (vmcnt(0) lgkmcnt(0) + barrier)
+    }
+
+    // ---- output transform (+ statistics) (+ add, bias, ReLU) + store: lane holds rows 4g..4g+3 of quad column r16 of its block
+    const bool stats = prm.stat_sum != nullptr;
+    float* red = pool;
+    if (stats) __syncthreads();
+    const int pos = pos0 + col;
+    const bool ok = pos < HW;
+    const int off0 = n_img * prm.M * prm.S + 4 * tq * HW + pos;        // frame 4*tq; the next three are HW further each
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * i + 4 * g + r;
+            const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
+            const float s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
+            float y[4] = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
+            float s1 = 0.f, s2 = 0.f;
+            if (ok && m < prm.M) {
+                s1 = (y[0] + y[1]) + (y[2] + y[3]);
+                s2 = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+                const int off = off0 + m * prm.S;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float yv = y[f];
+                    if (prm.add != nullptr) yv += prm.add[off + f * HW];
+                    if (prm.bias != nullptr) yv += prm.bias[m];
+                    if (prm.relu) yv = fmaxf(yv, 0.f);
+                    OUT[off + f * HW] = yv;
+                }
+            }
+            if (stats) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (r16 == 0) {
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2] = s1;
+                    red[(wave * BM + 16 * i + 4 * g + r) * 2 + 1] = s2;
+                }
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < prm.M) {
+            const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
+            const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
+            prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + ct] = t1;
+            prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + ct] = t2;
+        }
+    }
+#endif
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -918,7 +1128,7 @@ int wino_fwd_stat_tiles(const zsv_conv_desc* d) {
 static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_F43") == nullptr; }
 static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
     const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
-    if (winot_shape(d)) return wino_align((size_t)nblk * 4 * 16 * Mp * sizeof(float));            // (no row taps)
+    if (winot_shape(d)) return wino_align((size_t)nblk * 6 * 16 * Mp * sizeof(float));            // (no row taps; 6 points: the F(4,3) form, the F(2,3) form uses 4)
     const int points = wino_f43(d) ? 6 : 4;
     return wino_align((size_t)nblk * 3 * d->kT * points * 16 * Mp * sizeof(float));
 }
@@ -970,6 +1180,16 @@ static int winot_launch(const WinoParams& p, const float* up, const float* in, f
     return launch_status();
 }
 
+template <int TM, bool PRE>
+static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 260 + (PRE ? 256 : 0);               // as in the kernel
+    constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_winot4_kernel<TM, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    hipLaunchKernelGGL((conv_winot4_kernel<TM, PRE>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    return launch_status();
+}
+
 // the temporal form: M rows from C reduction channels; G[m][c][kt] = w[m*sm + c*sc + (flip ? 2 - kt : kt)]
 static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
                      const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, const float* pre_coef,
@@ -994,11 +1214,17 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
     p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
     float* up = (float*)workspace;
-    const long total = (long)p.nblk * 4 * 16 * p.Mp;
+    const bool f43 = getenv("ZSV_WINOT_NO_F43") == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
+    const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip, total);
+    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip,
+                       total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (f43) {
+        if (pre_coef) return tm == 3 ? winot4_launch<3, true>(p, up, in, out, stream) : winot4_launch<4, true>(p, up, in, out, stream);
+        return tm == 3 ? winot4_launch<3, false>(p, up, in, out, stream) : winot4_launch<4, false>(p, up, in, out, stream);
+    }
     if (pre_coef) return tm == 3 ? winot_launch<3, true>(p, up, in, out, stream) : winot_launch<4, true>(p, up, in, out, stream);
     return tm == 3 ? winot_launch<3, false>(p, up, in, out, stream) : winot_launch<4, false>(p, up, in, out, stream);
 }
