@@ -546,6 +546,13 @@ static int wgrad_twino_launch(const WgradTringParams& p, int slices, hipStream_t
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_twino_kernel<TM, PRE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    if (const char* e = getenv("ZSV_WGRAD_LDS_PAD")) {          // occupancy experiment: a bigger allocation = one workgroup per CU
+        const int bytes = LDS_BYTES + atoi(e);
+        if (hipFuncSetAttribute((const void*)conv_wgrad_twino_kernel<TM, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
+        hipLaunchKernelGGL((conv_wgrad_twino_kernel<TM, PRE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), bytes, stream, p, x,
+                           dy, out);
+        return launch_status();
+    }
     hipLaunchKernelGGL((conv_wgrad_twino_kernel<TM, PRE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, out);
     return launch_status();

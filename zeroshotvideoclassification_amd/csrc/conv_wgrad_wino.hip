@@ -354,6 +354,13 @@ static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t s
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, TN, EDGE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    if (const char* e = getenv("ZSV_WGRAD_LDS_PAD")) {          // occupancy experiment: a bigger allocation = one workgroup per CU
+        const int bytes = LDS_BYTES + atoi(e);
+        if (hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, TN, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
+        hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, TN, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), bytes, stream, p, x,
+                           dy, vm, out);
+        return launch_status();
+    }
     hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, TN, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, vm, out);
     return launch_status();
