@@ -995,3 +995,33 @@ def test_conv3d_stride2_dgrad_all_classes_in_one_launch(case, monkeypatch):
     close(merged, per_class.double(), rtol=5e-6, what=f"{name}: merged vs class-by-class launches")
     if cout >= 32:                                          # (short sums can round identically)
         assert not torch.equal(merged, per_class), "the two paths should not be the same kernel"
+
+
+@pytest.mark.parametrize("n,t,h,w,cout", [(2, 4, 56, 56, 45), (3, 2, 112, 112, 45), (1, 1, 8, 8, 45), (2, 3, 24, 40, 20), (2, 2, 30, 128, 48)],
+                         ids=["half_size", "full_frames", "one_tiny_frame", "fewer_output_channels", "longest_rows_odd_row_count"])
+def test_stem_weight_gradient_row_kernel(n, t, h, w, cout, monkeypatch):
+    """Weight gradient of the R(2+1)D stem (resnet.py:170: 3 -> 45, (1,7,7), stride (1,2,2), padding (0,3,3)) through
+    stem_wgrad_kernel (operands as rows, the seven input rows of an output row in a ring) against torch CPU fp64 and against
+    the generic per-element kernel."""
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, 3, t, h, w, generator=g)
+    wt = torch.randn(cout, 3, 1, 7, 7, generator=g) * 0.1
+    xr, wr = x.double(), wt.double().requires_grad_()
+    yr = F.conv3d(xr, wr, stride=(1, 2, 2), padding=(0, 3, 3))
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    def run():
+        xg, wg = x.to(DEV), wt.to(DEV).requires_grad_()
+        ops.conv3d(xg, wg, None, (1, 2, 2), (0, 3, 3)).backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        return wg.grad
+
+    rows = run()
+    close(rows, wr.grad, rtol=5e-5, what="stem wgrad (row kernel)")
+    assert torch.equal(rows, run()), "bitwise reproducible"
+    monkeypatch.setenv("ZSV_NO_STEM_WGRAD", "1")
+    generic = run()
+    close(rows, generic.double(), rtol=2e-5, what="row kernel vs generic kernel")
+    if n * t * h * w >= 4096:                                  # (sums of a few terms can round identically)
+        assert not torch.equal(rows, generic), "the two paths should not be the same kernel"

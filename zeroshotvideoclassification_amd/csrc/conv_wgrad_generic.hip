@@ -210,6 +210,178 @@ __global__ __launch_bounds__(256) void slab_sum_generic_kernel(const float* __re
     }
 }
 
+// ================================================================================================
+// The R(2+1)D stem's weight gradient (resnet.py:170: Conv3d(3, 45, (1,7,7), stride (1,2,2), padding (0,3,3))) with its operands as ROWS.
+// It is the last kernel of a training step and runs alone (its dY is the last gradient the backward produces), so its time is on the
+// critical path in full; the generic kernel above gathers every (ci, kh, kw) element of a voxel on its own (4-byte loads, a mask test
+// each) and reaches 28 TFLOP/s.  Here a chunk is one OUTPUT ROW (n, t, h'): k = w' (Wo / 4 MFMA steps),
+//     dW[co][ci][kh][kw] += sum_w' dY[co][n,t,h',w'] * X[ci][n,t, 2h'+kh-3, 2w'+kw-3]
+//   * A = the row of dY for every output channel ([48][Wo], 16-byte LDS-DMAs, four rows per instruction);
+//   * B = the seven input rows 2h'-3 .. 2h'+3 of the three channels, kept in a ring of 10 row slots per channel (consecutive output rows
+//     share five of them: two new rows per channel and chunk), each row one 16-byte LDS-DMA instruction into a zero-padded slot; a B
+//     fragment is read at stride 2 along the row (address 2w' + kw + 1), the row out of the image is a DMA that reads zeros;
+//   * columns = 3 x 64 (a channel's 49 taps padded to 64), wave w owns columns 16w .. 16w+15 of each channel, 3 x 3 accumulator tiles;
+//   * a workgroup walks `rows` consecutive output rows of one frame and writes its partial dW in the weight tensor's own layout; the
+//     partials are added in a fixed order by slab_sum_generic_kernel.
+struct StemWgradParams {
+    int N, T, Ho, Wo, Hi, Wi, Cout;
+    int rows, parts;                 // output rows per workgroup, workgroups per frame
+    unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams prm, const float* __restrict__ X, const float* __restrict__ DY,
+                                                         float* __restrict__ OUT) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    constexpr int XS = 10, XP = 264;            // ring slots per channel, floats per slot (64 lanes x 16 B + 8: consecutive slots 8 banks apart)
+    constexpr int AB = 260;                     // floats per block of four dY rows (one DMA instruction + 4)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    __shared__ __attribute__((aligned(16))) float xs[3 * XS * XP];
+    __shared__ __attribute__((aligned(16))) float as_[2][12 * AB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, r16 = lane & 15;
+    const int frame = blockIdx.x / prm.parts, part = blockIdx.x - frame * prm.parts;
+    const int n = frame / prm.T, t = frame - n * prm.T;
+    const int h0 = part * prm.rows, h1 = min(prm.Ho, h0 + prm.rows);
+    const int pa = prm.Wo >> 2, px = prm.Wi >> 2;          // 16-byte pieces per dY row / X row
+
+    for (int i = tid; i < 3 * XS * XP; i += 256) xs[i] = 0.f;       // (the left pad of every slot stays zero for good)
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, prm.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY), 0, prm.dy_bytes, 0x00020000);
+    // X row rr (= input row + 3) of channel ci = wave: lanes 0 .. px-1 carry the row, the others read zeros (the slot's right pad)
+    const long x_plane = ((long)(n * 3 + wave) * prm.T + t) * prm.Hi * prm.Wi;
+    auto issue_x = [&](int rr) {
+        if (wave >= 3) return;
+        const int xr = rr - 3;
+        const unsigned off = (lane < px && xr >= 0 && xr < prm.Hi) ? (unsigned)(4 * (x_plane + (long)xr * prm.Wi + 4 * lane)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr_t)(xs + (wave * XS + rr % XS) * XP + 4), 16, (int)off, 0, 0, 0);
+    };
+    // dY row h' of output channels 4b .. 4b+3, b = wave, wave + 4, wave + 8: lane = (row lane / pa, piece lane % pa)
+    const int a_row = lane / pa, a_piece = lane - a_row * pa;
+    auto issue_dy = [&](int hh, int buf) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int b = wave + 4 * j, co = 4 * b + a_row;
+            const unsigned off = (a_row < 4 && co < prm.Cout)
+                ? (unsigned)(4 * ((((long)(n * prm.Cout + co) * prm.T + t) * prm.Ho + hh) * prm.Wo + 4 * a_piece)) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_ptr_t)(&as_[buf][b * AB]), 16, (int)off, 0, 0, 0);
+        }
+    };
+
+    // this lane's fragment columns: q = 16 * wave + r16 of every channel -> tap (kh, kw) (the padding columns 49..63 read tap 0 and are dropped)
+    const int q = 16 * wave + r16, qq = q < 49 ? q : 0, kh = qq / 7, kw = qq - 7 * kh;
+    int a_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int co = 16 * i + r16;
+        a_off[i] = (co >> 2) * AB + (co & 3) * (4 * pa) + g;
+    }
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (h0 < h1) {
+        for (int r = 0; r < 7; ++r) issue_x(2 * h0 + r);
+        issue_dy(h0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ksteps = prm.Wo >> 2;
+    for (int hh = h0; hh < h1; ++hh) {
+        const int cur = (hh - h0) & 1;
+        if (hh + 1 < h1) {
+            issue_x(2 * hh + 7);
+            issue_x(2 * hh + 8);
+            issue_dy(hh + 1, cur ^ 1);
+        }
+        const float* as = as_[cur];
+        int b_off[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b_off[j] = (j * XS + (2 * hh + kh) % XS) * XP + kw + 1 + 2 * g;
+        float a[2][3], b[2][3];
+        auto fetch = [&](int s, int slot) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[slot][i] = as[a_off[i] + 4 * s];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b[slot][j] = xs[b_off[j] + 8 * s];
+        };
+        fetch(0, 0);
+        for (int s = 0; s < ksteps; s += 2) {                       // (two steps per trip: the fragment slots stay compile-time)
+            if (s + 1 < ksteps) fetch(s + 1, 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+            if (s + 1 < ksteps) {
+                if (s + 2 < ksteps) fetch(s + 2, 0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // partial dW of this workgroup, in the weight tensor's layout [co][ci][kh][kw]; acc[i][j][r]: co = 16 i + 4 g + r, column q of channel j
+    float* out = OUT + (size_t)blockIdx.x * prm.Cout * 147;
+    if (q < 49) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * i + 4 * g + r;
+                if (co < prm.Cout) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) out[co * 147 + j * 49 + q] = acc[i][j][r];
+                }
+            }
+    }
+#endif
+}
+
+static bool stem_wgrad_shape(const zsv_conv_desc* d) {
+    if (getenv("ZSV_NO_STEM_WGRAD")) return false;
+    if (d->Cin != 3 || d->kT != 1 || d->sT != 1 || d->pT != 0 || d->kH != 7 || d->kW != 7 || d->sH != 2 || d->sW != 2 || d->pH != 3 || d->pW != 3)
+        return false;
+    if (d->Hi % 2 != 0 || d->Wi % 4 != 0 || d->Wo != d->Wi / 2 || d->Ho != d->Hi / 2 || d->Wo % 4 != 0) return false;
+    if (d->Wo > 64 || d->Cout > 48 || d->Cout < 1) return false;          // four dY rows per DMA instruction: 4 * Wo / 4 <= 64 lanes
+    if ((long)d->N * d->Cout * d->To * d->Ho * d->Wo >= (1L << 29) || (long)d->N * 3 * d->Ti * d->Hi * d->Wi >= (1L << 29)) return false;
+    return true;
+}
+// workgroups per frame: ~1400 in all (2.75 rounds of the 512 resident ones measured best at 352 frames: 0.24 ms against 0.25-0.28 for 1056, 2112,
+// 2816), at least 8 output rows each, and an even split of the rows where one is near
+static int stem_wgrad_parts(const zsv_conv_desc* d) {
+    const long frames = (long)d->N * d->To;
+    long target = 1408;
+    if (const char* e = getenv("ZSV_STEM_WGRAD_WGS")) target = atol(e) > 0 ? atol(e) : target;
+    long parts = (target + frames - 1) / frames;
+    const long maxp = (d->Ho + 7) / 8;
+    if (parts > maxp) parts = maxp;
+    if (parts < 1) parts = 1;
+    for (long q = parts; q * 2 > parts && q >= 1; --q)
+        if (d->Ho % q == 0) { parts = q; break; }
+    const long rows = (d->Ho + parts - 1) / parts;
+    return (int)((d->Ho + rows - 1) / rows);
+}
+
+// first level of a two-level slab sum: block row c adds slabs [c * per, (c + 1) * per) into part[c][i] (fixed order)
+__global__ __launch_bounds__(256) void slab_sum_chunks_kernel(const float* __restrict__ slabs, float* __restrict__ part, long n, int slices,
+                                                              int per) {
+    const int c = blockIdx.y, k0 = c * per, k1 = min(slices, k0 + per);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = k0; k < k1; ++k) s += slabs[(size_t)k * n + i];
+        part[(size_t)c * n + i] = s;
+    }
+}
+
 struct WgradGenPlan {
     int cfg;        // 0: 128x128, 1: 64x128 (small Cout), 2: 144x64
     int tiles_m, tiles_n, slices, chunks_per_slice;
@@ -240,16 +412,51 @@ static WgradGenPlan wgrad_gen_plan(const zsv_conv_desc* d) {
 }
 
 
-size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d) {
+static size_t wgrad_gen_plan_bytes(const zsv_conv_desc* d) {
     const WgradGenPlan pl = wgrad_gen_plan(d);
     if (pl.slices <= 1) return 0;
     return (size_t)pl.slices * d->Cout * d->Cin * d->kT * d->kH * d->kW * sizeof(float);
 }
+// slabs of the workgroups + the 32 partial sums of the first reduction level
+static size_t stem_wgrad_bytes(const zsv_conv_desc* d) { return ((size_t)d->N * d->To * stem_wgrad_parts(d) + 32) * d->Cout * 147 * sizeof(float); }
+
+size_t wgrad_generic_workspace_bytes(const zsv_conv_desc* d) {
+    const size_t gen = wgrad_gen_plan_bytes(d);
+    if (!stem_wgrad_shape(d)) return gen;
+    const size_t stem = stem_wgrad_bytes(d);            // (the generic kernel still serves unaligned tensors of this shape)
+    return stem > gen ? stem : gen;
+}
 
 int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
+    if (stem_wgrad_shape(d) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+        if (!workspace || workspace_bytes < stem_wgrad_bytes(d)) return ZSV_E_WORKSPACE;
+        StemWgradParams p;
+        p.N = d->N; p.T = d->To; p.Ho = d->Ho; p.Wo = d->Wo; p.Hi = d->Hi; p.Wi = d->Wi; p.Cout = d->Cout;
+        p.parts = stem_wgrad_parts(d);
+        p.rows = (d->Ho + p.parts - 1) / p.parts;
+        p.x_bytes = 4u * (unsigned)((long)d->N * 3 * d->Ti * d->Hi * d->Wi);
+        p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * d->To * d->Ho * d->Wo);
+        const long wgs = (long)d->N * d->To * p.parts;
+        hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, p, x, dy, (float*)workspace);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+        const long n = (long)d->Cout * 147;
+        const long blocks = (n + 31) / 32;
+        if (wgs <= 64) {
+            hipLaunchKernelGGL(slab_sum_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, n, (int)wgs);
+            return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+        }
+        // two levels, both in a fixed order: 32 chunks of slabs, then the 32 partial sums
+        float* part = (float*)workspace + (size_t)wgs * n;
+        const int per = (int)((wgs + 31) / 32), chunks = (int)((wgs + per - 1) / per);
+        hipLaunchKernelGGL(slab_sum_chunks_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)chunks), dim3(256), 0, stream, (const float*)workspace,
+                           part, n, (int)wgs, per);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+        hipLaunchKernelGGL(slab_sum_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)part, dw, n, chunks);
+        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+    }
     const WgradGenPlan pl = wgrad_gen_plan(d);
-    const size_t need = wgrad_generic_workspace_bytes(d);
+    const size_t need = wgrad_gen_plan_bytes(d);
     if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
     WgradGenParams p;
     p.M = d->Cout;
