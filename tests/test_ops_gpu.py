@@ -1025,3 +1025,44 @@ def test_stem_weight_gradient_row_kernel(n, t, h, w, cout, monkeypatch):
     close(rows, generic.double(), rtol=2e-5, what="row kernel vs generic kernel")
     if n * t * h * w >= 4096:                                  # (sums of a few terms can round identically)
         assert not torch.equal(rows, generic), "the two paths should not be the same kernel"
+
+
+def test_conv3d_r2plus1d_family_fuzz():
+    """Random extents / channel counts of the geometries that have kernels of their own -- the strided 1x3x3 and 3x1x1 convolutions
+    (all residue classes in one launch), the stride-1 temporal convolution on whole frame quads (Winograd along T, incl. ragged
+    position segments), the 1x3x3 stride-1 convolution (Winograd along W) and the 3-channel 7x7 stem (row kernel for its wgrad):
+    forward, input gradient and weight gradient through ops.conv3d against torch CPU fp64."""
+    rng = np.random.default_rng(77)
+    g = torch.Generator().manual_seed(123)
+    chans = [16, 24, 45, 64, 70, 128, 144, 230]
+    cases = []
+    for _ in range(6):      # strided spatial
+        cases.append(((1, 3, 3), (1, 2, 2), (0, 1, 1), int(rng.integers(1, 4)), int(rng.choice(chans)), int(rng.choice(chans)),
+                      (int(rng.integers(1, 6)), 2 * int(rng.integers(1, 21)), 2 * int(rng.integers(1, 21)))))
+    for _ in range(5):      # strided temporal
+        cases.append(((3, 1, 1), (2, 1, 1), (1, 0, 0), int(rng.integers(1, 4)), int(rng.choice(chans)), int(rng.choice(chans)),
+                      (2 * int(rng.integers(1, 7)), int(rng.integers(1, 15)), int(rng.integers(1, 15)))))
+    for _ in range(6):      # stride-1 temporal, T in {4, 8, 16}, H*W % 4 == 0, enough tiles for the Winograd path
+        t = int(rng.choice([4, 8, 16]))
+        cases.append(((3, 1, 1), (1, 1, 1), (1, 0, 0), int(rng.integers(3, 7)), int(rng.choice(chans)), int(rng.choice(chans)),
+                      (t, 2 * int(rng.integers(10, 25)), 2 * int(rng.integers(10, 25)))))
+    for _ in range(4):      # stride-1 spatial, even W (F(2,3)) or W % 4 == 0 (F(4,3))
+        cases.append(((1, 3, 3), (1, 1, 1), (0, 1, 1), int(rng.integers(2, 5)), int(rng.choice(chans)), int(rng.choice(chans)),
+                      (int(rng.integers(2, 7)), int(rng.integers(20, 50)), 2 * int(rng.integers(12, 40)))))
+    for _ in range(4):      # 3-channel stem, Wo % 4 == 0
+        cases.append(((1, 7, 7), (1, 2, 2), (0, 3, 3), int(rng.integers(1, 4)), 3, int(rng.choice([16, 45, 48])),
+                      (int(rng.integers(1, 5)), 2 * int(rng.integers(2, 30)), 8 * int(rng.integers(1, 16)))))
+    for k, s, p, n, cin, cout, dims in cases:
+        x = torch.randn(n, cin, *dims, generator=g)
+        wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+        xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+        yr = F.conv3d(xr, wr, None, stride=s, padding=p)
+        dy = torch.randn(yr.shape, generator=g)
+        yr.backward(dy.double())
+        xg, wg = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+        tag = f"n{n} c{cin}->{cout} k{k} s{s} p{p} in{dims}"
+        yg = ops.conv3d(xg, wg, None, s, p)
+        close(yg, yr, rtol=3e-5, what=tag + " fwd")
+        yg.backward(dy.to(DEV))
+        close(xg.grad, xr.grad, rtol=3e-5, what=tag + " dgrad")
+        close(wg.grad, wr.grad, rtol=5e-5, what=tag + " wgrad")
