@@ -9,16 +9,21 @@ A "step" is main.py:170-203 of the reference: zero_grad -> forward -> MSE -> bac
 Adam, on 22 synthetic clips (3x16x112x112, fp32) per GPU with random-init weights
 (BASELINE.json configs[1]; per-GPU batch fixed => weak scaling); with N > 1 the gradients are
 averaged across ranks by the bucketed RCCL all-reduce of ``ddp.GradientSync``, overlapped
-with backward.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
-line.  Extra objects on that line:
+with backward.  Inputs are resident in HBM before the timed region (``--input u8`` instead
+streams uint8 frames over PCIe every step and runs the clip transform on the device: the
+PCIe-inclusive rate, never the headline).  Rank 0 prints ONE JSON line.  Extra objects on it:
 
 * ``roofline``  : the dominant kernel (the fp32-MFMA convolution on the 64->144 1x3x3 shape,
-  41 % of forward FLOPs; kw taps in Winograd F(4,3) form): algorithmic (direct-convolution)
-  FLOPs per launch / mean launch duration from HIP events recorded on the launch stream inside
-  the timed steps, against the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md); the FLOPs
-  the matrix pipe really executes (1/2 of them) are reported next to it;
+  41 % of forward FLOPs; kw taps in Winograd F(4,3) form).  ``achieved`` / ``frac`` are the
+  FLOPs the matrix pipe EXECUTES (half the direct-convolution count) / mean launch duration
+  from HIP events recorded on the launch stream inside the timed steps, against the
+  157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md): a physical fraction <= 1.  The
+  direct-convolution (algorithmic) rate SURVEY 8d counts is ``algorithmic_tflops``;
 * ``cpu_baseline``: the CPU oracle (oracle/restatement.py, pinned to the reference) timed on
-  this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only.
+  this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only;
+* ``host_enqueue_ms``: host time to queue one step's launches (no device sync inside);
+* ``extra``: after everything else, N = 1 only: BASELINE.json configs[3] (C3D training step)
+  and configs[4]'s per-GPU work (32-frame bf16 ``evaluate()`` protocol), 5 steps / 6 batches each.
 """
 from __future__ import annotations
 
@@ -27,6 +32,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -42,18 +48,24 @@ T_START = time.perf_counter()
 CLIPS_PER_GPU = 22
 FRAMES, SIZE = 16, 112
 FP32_MFMA_PEAK_TFLOPS = 157.3
+DEFAULT_TIMEOUT_S = 420.0
 # S1 of SURVEY section 2a: Conv3d(64, 144, (1,3,3), stride 1, pad (0,1,1)) on 16x56x56
 S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56)
-# the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step
+# the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step;
+# `mfma_saving`: direct-convolution MACs / MACs the Winograd F(4,3)-along-W form executes (12 -> 6 per 4 outputs)
 DOMINANT = {
-    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino4_kernel<3, 12>",
+    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino4_kernel<3, 12>", mfma_saving=2.0,
+                        pmc_key="conv_wino4_kernel<3, 12>",
                         what="Conv3d(64,144,(1,3,3)) forward @16x56x56 (resnet.py:40-45, layer1 spatial half of Conv2Plus1D)"),
     # network.py:105 conv2 = Conv3d(64,128,3x3x3, pad 1) after pool1 (1,2,2): 22.2 GFLOP/clip, 29 % of C3D's forward FLOPs
     "c3d": dict(geometry=dict(Cin=64, Cout=128, kT=3, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56), launches=1,
-                symbol="zsv::conv_wino4_kernel<4, 0>",
+                symbol="zsv::conv_wino4_kernel<4, 0>", mfma_saving=2.0, pmc_key=None,
                 what="Conv3d(64,128,3x3x3) forward @16x56x56 (network.py:105 conv2)"),
 }
 BASELINE_CONFIG = {"r2plus1d_18": "BASELINE.json configs[1]; configs[2] when n_gpus > 1", "c3d": "BASELINE.json configs[3]"}
+# committed PMC passes of the dominant kernel, newest first (counters cannot be read inside this process)
+PMC_BUSY_FILES = ("r03_s1_mfma_busy.json", "r02_s1_mfma_busy.json")
+PMC_TRAFFIC_FILES = ("r03_s1_hbm_traffic.json", "r02_s1_hbm_traffic.json")
 
 
 def free_port() -> int:
@@ -75,39 +87,106 @@ def child_commands(n_gpus: int, argv, port: int, script: str = os.path.abspath(_
     return jobs
 
 
-def launch_children(n_gpus: int, argv) -> int:
-    """``python bench.py --gpus N`` without a launcher: start one fresh process per GPU (the reference's
-    ``opt.bs *= n_gpu`` + ``nn.DataParallel``, main.py:61-63,126, becomes one rank per device).  The parent
-    never touches the GPU (``device_count()`` does not initialise it on this image) and never execs; rank
-    0's stdout -- the one JSON line -- is this process's stdout.  Non-zero exit if any rank fails."""
-    import subprocess
-    have = torch.cuda.device_count()
-    if os.environ.get("ZSV_BENCH_SAME_DEVICE"):          # rehearsal on a one-GPU box: every rank on cuda:0, gloo transport
-        have = max(have, n_gpus)
-    if have < n_gpus:
-        print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
-        return 2
-    procs = []
-    for cmd, extra in child_commands(n_gpus, argv, free_port()):
-        env = dict(os.environ)
-        env.update(extra)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=None if extra["RANK"] == "0" else subprocess.DEVNULL))
+def supervise(procs, timeout_s: float, poll_s: float = 0.2, grace_s: float = 5.0, label=lambda i: f"rank {i}") -> int:
+    """Wait for the started ranks (``procs``: list of ``subprocess.Popen``).  First non-zero exit: the other ranks
+    (left waiting in a collective) are terminated.  Past ``timeout_s`` the ranks still running are terminated, after
+    ``grace_s`` killed, and the return code is 124 with the stuck ranks named on stderr.  Never blocks forever."""
+    deadline = time.monotonic() + float(timeout_s)
+    alive = dict(enumerate(procs))
     failed = 0
-    while procs:
-        for p in list(procs):
+    timed_out = False
+    kill_at = None
+    while alive:
+        for i, p in list(alive.items()):
             rc = p.poll()
             if rc is None:
                 continue
-            procs.remove(p)
-            if rc != 0 and not failed:
+            del alive[i]
+            if rc != 0 and not failed and not timed_out:
                 failed = rc
-                for q in procs:                       # a dead rank leaves the others waiting in a collective
+                print(f"bench.py: {label(i)} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive.values():
                     q.terminate()
-        time.sleep(0.2)
-    return failed
+                kill_at = time.monotonic() + grace_s
+        now = time.monotonic()
+        if alive and not timed_out and not failed and now > deadline:
+            timed_out = True
+            stuck = ", ".join(label(i) for i in sorted(alive))
+            print(f"bench.py: no result after {timeout_s:.0f} s (--timeout): {stuck} still running "
+                  "(hung in a collective or in a kernel?); terminating", file=sys.stderr, flush=True)
+            for q in alive.values():
+                q.terminate()
+            kill_at = now + grace_s
+        if alive and kill_at is not None and now > kill_at:
+            for q in alive.values():
+                q.kill()
+            kill_at = now + grace_s
+        if alive:
+            time.sleep(poll_s)
+    return 124 if timed_out else failed
 
 
-def parse():
+def launch_children(n_gpus: int, argv, timeout_s: float = DEFAULT_TIMEOUT_S, script: str = os.path.abspath(__file__),
+                    need_devices: bool = True) -> int:
+    """``python bench.py --gpus N`` without a launcher: start one fresh process per GPU (the reference's
+    ``opt.bs *= n_gpu`` + ``nn.DataParallel``, main.py:61-63,126, becomes one rank per device).  The parent
+    never touches the GPU (``device_count()`` does not initialise it on this image) and never execs; rank
+    0's stdout -- the one JSON line -- is this process's stdout.  Non-zero exit if any rank fails or the
+    deadline passes (``supervise``)."""
+    import subprocess
+    if need_devices:
+        have = torch.cuda.device_count()
+        if os.environ.get("ZSV_BENCH_SAME_DEVICE"):          # rehearsal on a one-GPU box: every rank on cuda:0, gloo transport
+            have = max(have, n_gpus)
+        if have < n_gpus:
+            print(f"bench.py: --gpus {n_gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
+            return 2
+    procs = []
+    for cmd, extra in child_commands(n_gpus, argv, free_port(), script):
+        env = dict(os.environ)
+        env.update(extra)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if extra["RANK"] == "0" else subprocess.DEVNULL))
+    return supervise(procs, timeout_s)
+
+
+def rank_core_slice(cores, local_rank: int, local_world: int):
+    """The cores rank ``local_rank`` of ``local_world`` keeps: a contiguous slice of the sorted allowed set (ranks
+    do not fight for cores; neighbouring GPUs usually share a socket with neighbouring core numbers).  With fewer
+    cores than ranks every rank keeps the whole set.  Pure function (tested on CPU)."""
+    cores = sorted(cores)
+    if local_world <= 1 or len(cores) < 2 * local_world:
+        return cores
+    per = len(cores) // local_world
+    return cores[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank_to_cores(local_rank: int, local_world: int):
+    if os.environ.get("ZSV_BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        mine = rank_core_slice(os.sched_getaffinity(0), local_rank, local_world)
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 8)))
+        return mine
+    except OSError:
+        return None
+
+
+def start_watchdog(timeout_s: float, rank: int):
+    """Under ``torch.distributed.run`` nobody supervises the ranks: a rank that is still alive ``timeout_s`` after
+    its start reports and exits with code 124 (``os._exit``: a hung collective cannot be unwound), which makes the
+    launcher stop the others."""
+    def fire():
+        print(f"bench.py: rank {rank} still running after {timeout_s:.0f} s (--timeout): giving up "
+              "(hung in a collective or in a kernel?)", file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(float(timeout_s), fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -117,9 +196,16 @@ def parse():
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="torch",
                     help="fused: zeroshotvideoclassification_amd.optim.FusedAdam (one launch, same update rule as "
                          "torch.optim.Adam); torch: torch.optim.Adam")
+    ap.add_argument("--input", choices=["resident", "u8"], default="resident",
+                    help="resident: fp32 clips already in HBM (the headline); u8: pinned uint8 frames (N,T,H,W,3) -> async "
+                         "H2D on a copy stream (double-buffered) -> zsv_clip_transform -> step, every step")
+    ap.add_argument("--input-hw", default="128x171", help="frame size of the uint8 source clips for --input u8")
+    ap.add_argument("--timeout", type=float, default=DEFAULT_TIMEOUT_S,
+                    help="seconds after which ranks that are still running are stopped and the run fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3D / 32-frame bf16 eval legs after the timed region")
     ap.add_argument("--cpu-steps", type=int, default=12)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def log(msg: str) -> None:
@@ -151,18 +237,62 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("ZSV_CPU_THREADS", "64"))))
 
 
-def pmc_traffic(n_clips: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r02_s1_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc runs of
-    tools/conv_bench.py at N = 22).  Counters cannot be read inside this process; None when the
-    batch differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_s1_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"]["conv_wino4_kernel<3, 12>"]
-        return round(k["hbm_bytes"]) if n_clips == CLIPS_PER_GPU else None
-    except Exception:
+def _profile_entry(files, key):
+    for name in files:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][key], name
+        except Exception:
+            continue
+    return None, None
+
+
+def pmc_traffic(dom, n_clips: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    separate rocprofv3 --pmc runs of tools/conv_bench.py at N = 22).  None when the batch differs from the
+    profiled one or no pass is committed for this kernel."""
+    if not dom.get("pmc_key") or n_clips != CLIPS_PER_GPU:
         return None
+    k, _ = _profile_entry(PMC_TRAFFIC_FILES, dom["pmc_key"])
+    return round(k["hbm_bytes"]) if k and "hbm_bytes" in k else None
+
+
+def pmc_busy(dom):
+    """(matrix-pipe busy fraction, sustained clock in GHz, file) of the dominant kernel from the committed
+    ``--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`` pass."""
+    if not dom.get("pmc_key"):
+        return None, None, None
+    k, name = _profile_entry(PMC_BUSY_FILES, dom["pmc_key"])
+    if not k:
+        return None, None, None
+    return k.get("mfma_pipe_utilisation"), k.get("clock_GHz"), name
+
+
+def roofline_entry(dom, n_clips: int, durations_ms):
+    """The ``roofline`` object of the JSON line for the dominant kernel (pure function of the measured launch
+    durations; tested on CPU).  ``frac`` = executed matrix-pipe FLOPs / peak: a physical fraction."""
+    mean_ms = sum(durations_ms) / len(durations_ms)
+    gm = dom["geometry"]
+    taps = gm["kT"] * gm["kH"] * gm["kW"]
+    voxels = gm["Ti"] * gm["Hi"] * gm["Wi"]                 # stride 1, "same" padding: output voxels = input voxels
+    flops = 2.0 * n_clips * gm["Cout"] * gm["Cin"] * taps * voxels   # direct-convolution count (S1: 8.324 GFLOP/clip, SURVEY 8d)
+    alg_bytes = 4.0 * (n_clips * gm["Cin"] * voxels + n_clips * gm["Cout"] * voxels + gm["Cout"] * gm["Cin"] * taps)
+    algorithmic = flops / (mean_ms * 1e-3) / 1e12
+    executed = algorithmic / dom["mfma_saving"]
+    busy, clock, src = pmc_busy(dom)
+    return {"kernel": f"{dom['symbol']} = {dom['what']} (fp32 Winograd F(4,3) along W + its weight-transform launch), "
+                      f"{dom['launches']} launch(es)/step",
+            "bound": "mfma", "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+            "achieved_is": "FLOPs the matrix pipe executes (direct-convolution FLOPs / speedup_vs_direct; counter-checked: "
+                           "SQ_VALU_MFMA_BUSY_CYCLES is exactly 1/2 of the direct kernel's) / mean launch time, against the "
+                           "2.4 GHz peak",
+            "algorithmic_tflops": round(algorithmic, 2), "speedup_vs_direct": dom["mfma_saving"],
+            "algorithmic_flops_per_launch": flops,
+            "mfma_busy": busy, "sustained_clock_ghz": clock, "pmc_source": (f"profiles/{src}" if src else None),
+            "launches_timed": len(durations_ms), "mean_launch_ms": round(mean_ms, 4),
+            "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
+            "traffic": pmc_traffic(dom, n_clips)}
 
 
 def cpu_baseline(network: str, steps: int):
@@ -193,17 +323,125 @@ def cpu_baseline(network: str, steps: int):
                       "in the build container (tests/golden)"}
 
 
+class U8Feeder:
+    """``--input u8``: the input side of main.py:167 on the device.  Two pinned uint8 clip batches ``(N,T,H,W,3)``
+    (what the reference's dataset workers produce before ``auxiliary/transforms.py:41-56``) alternate; batch i+1
+    crosses PCIe on a copy stream while step i computes; ``preprocess.ClipTransform`` (one HIP kernel: normalise,
+    THWC->CTHW, bilinear resize, crop, flip) writes the fp32 model input on the compute stream."""
+
+    def __init__(self, n, frames, h, w, dev, rank=0):
+        from zeroshotvideoclassification_amd import preprocess
+        g = torch.Generator().manual_seed(4242 + rank)
+        self.host = [torch.randint(0, 256, (n, frames, h, w, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        self.dev = [torch.empty_like(hst, device=dev) for hst in self.host]
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.copied = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [None, None]
+        self.transform = preprocess.get_transform(False, SIZE)
+        self.bytes_per_step = self.host[0].numel()
+        self.issued = 0
+        self.taken = 0
+
+    def prefetch(self):
+        slot = self.issued % 2
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])          # the transform of two steps ago has read the slot
+            self.dev[slot].copy_(self.host[slot], non_blocking=True)
+            self.copied[slot].record(self.copy_stream)
+        self.issued += 1
+
+    def next(self):
+        if self.issued == self.taken:
+            self.prefetch()
+        slot = self.taken % 2
+        self.taken += 1
+        self.prefetch()                                                  # the next batch travels while this one computes
+        main = torch.cuda.current_stream()
+        main.wait_event(self.copied[slot])
+        x = self.transform(self.dev[slot])                               # (N, 3, T, 112, 112) fp32
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.consumed[slot] = ev
+        return x.unsqueeze(1)
+
+
+def extra_c3d(dev, steps=5, warmup=2):
+    """BASELINE.json configs[3] for the driver's record: C3D training step at 22 clips (network.py:95-180)."""
+    from types import SimpleNamespace
+    from zeroshotvideoclassification_amd import network, ops, synthetic, train
+    model = network.get_network(SimpleNamespace(network="c3d", fixconvs=False, nopretrained=True))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
+    model.to(dev).train()
+    criterion = torch.nn.MSELoss().to(dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x = synthetic.synthetic_clips(CLIPS_PER_GPU, FRAMES, SIZE).to(dev)
+    _, z = synthetic.synthetic_targets(CLIPS_PER_GPU)
+    z = z.to(dev)
+    for _ in range(warmup):
+        train.train_step(model, optimizer, criterion, x, z)
+    dom = DOMINANT["c3d"]
+    timer = ops.KernelTimer("conv_fwd", dict(dom["geometry"], N=CLIPS_PER_GPU))
+    ops.KERNEL_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, loss = train.train_step(model, optimizer, criterion, x, z)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    out = {"workload": f"c3d training step (zero_grad+fwd+MSE+bwd+Adam), {CLIPS_PER_GPU} clips 3x{FRAMES}x{SIZE}x{SIZE}, fp32 "
+                       "(BASELINE.json configs[3])",
+           "value": round(CLIPS_PER_GPU * steps / dt, 2), "unit": "clips/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(1e3 * dt / steps, 3), "final_loss": float(loss.item())}
+    if timer.pairs:
+        r = roofline_entry(dom, CLIPS_PER_GPU, timer.durations_ms())
+        out["dominant_kernel"] = {k: r[k] for k in ("kernel", "achieved", "frac", "algorithmic_tflops", "mean_launch_ms", "unit")}
+    return out
+
+
+def extra_eval_t32_bf16(dev, batches=6):
+    """BASELINE.json configs[4] per GPU: the reference's ``evaluate()`` protocol (main.py:224-313) on 32-frame clips
+    with the bf16 engine: eval forward + cosine nearest class + the 10 half-class splits, three class tables."""
+    from types import SimpleNamespace
+    from zeroshotvideoclassification_amd import network, synthetic, train
+    model = network.get_network(SimpleNamespace(network="r2plus1d_18", fixconvs=False, nopretrained=False))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=True))
+    model.to(dev).eval()
+    res = {}
+    for name, ncls in (("ucf101", 101), ("hmdb51", 51), ("activitynet", 200)):
+        table = synthetic.class_table(ncls, seed=1000 + ncls)
+        data = []
+        for i in range(batches):
+            x = synthetic.synthetic_clips(CLIPS_PER_GPU, 32, SIZE, seed=7000 + i).to(dev)
+            labels, z = synthetic.synthetic_targets(CLIPS_PER_GPU, ncls, seed=1000 + ncls, rank=i)
+            data.append((x, labels, z))
+        train.evaluate(model, data[:1], table, device=dev, splits=0, dtype=torch.bfloat16)      # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = train.evaluate(model, data, table, device=dev, dtype=torch.bfloat16)
+        torch.cuda.synchronize()
+        res[name] = {"clips_per_s": round(r["n"] / (time.perf_counter() - t0), 1), "n": r["n"], "classes": ncls}
+    rates = [v["clips_per_s"] for v in res.values()]
+    return {"workload": f"R(2+1)D-18 evaluate() protocol, {batches} batches x {CLIPS_PER_GPU} clips 3x32x{SIZE}x{SIZE}, bf16 engine "
+                        "(BatchNorm folded), cosine nearest class + 10 half-class splits (BASELINE.json configs[4], one GPU's share)",
+            "value": round(statistics.mean(rates), 1), "unit": "clips/s", "per_table": res}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit(launch_children(args.gpus, sys.argv[1:]))
+        raise SystemExit(launch_children(args.gpus, sys.argv[1:], args.timeout))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    watchdog = start_watchdog(args.timeout, rank) if world > 1 else None
+    cores = pin_rank_to_cores(local_rank, local_world) if world > 1 else None
 
     from zeroshotvideoclassification_amd import _lib, ddp, network, ops, optim, synthetic, train
     from types import SimpleNamespace
@@ -236,9 +474,18 @@ def main():
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=1e-3)
 
-    x = synthetic.synthetic_clips(args.batch, FRAMES, SIZE, rank=rank).to(dev)
+    feeder = None
+    if args.input == "u8":
+        h, w = (int(v) for v in args.input_hw.lower().split("x"))
+        feeder = U8Feeder(args.batch, FRAMES, h, w, dev, rank)
+        x = None
+    else:
+        x = synthetic.synthetic_clips(args.batch, FRAMES, SIZE, rank=rank).to(dev)
     _, z = synthetic.synthetic_targets(args.batch, rank=rank)
     z = z.to(dev)
+
+    def step():
+        return train.train_step(model, optimizer, criterion, feeder.next() if feeder is not None else x, z, sync)
 
     def barrier():
         torch.cuda.synchronize()
@@ -246,9 +493,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"model on {dev}, world {world}; warm-up {args.warmup} steps")
+    log(f"model on {dev}, world {world}; warm-up {args.warmup} steps" + (f"; cores {cores[0]}..{cores[-1]}" if cores else ""))
     for i in range(args.warmup):
-        train.train_step(model, optimizer, criterion, x, z, sync)
+        step()
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     dom = DOMINANT.get(args.network)
@@ -258,20 +505,31 @@ def main():
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
-        _, loss = train.train_step(model, optimizer, criterion, x, z, sync)
+        _, loss = step()
+    t_queued = time.perf_counter() - t0                  # every launch of the K steps is queued; nothing was awaited
     barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
-    log(f"timed {args.steps} steps in {elapsed:.3f}s")
+    log(f"timed {args.steps} steps in {elapsed:.3f}s (host had queued them after {t_queued:.3f}s)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # host time to queue ONE step on an idle queue (no back-pressure from a full HIP queue): after the timed region
+    enqueue = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        step()
+        enqueue.append(time.perf_counter() - t)
+    barrier()
+    host_enqueue_ms = 1e3 * statistics.median(enqueue)
+
     # SURVEY 8d also asks for the forward-only and forward+backward times: measured AFTER the timed
     # region (N = 1 only), never part of `value`
     phases = None
-    if world == 1:
+    if world == 1 and feeder is None:
         def timed(fn, iters=5):
             fn()
             torch.cuda.synchronize()
@@ -295,17 +553,20 @@ def main():
     if rank == 0:
         total_clips = world * args.batch * args.steps
         value = total_clips / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
         label = {"r2plus1d_18": "R(2+1)D-18", "c3d": "C3D", "r3d_18": "R3D-18"}.get(args.network, args.network)
         which = BASELINE_CONFIG.get(args.network, "not a BASELINE.json config")
         if args.network == "r2plus1d_18":
             which = "BASELINE.json configs[1]" if world == 1 else f"BASELINE.json configs[2] at {world} GPUs"
         if args.batch != CLIPS_PER_GPU:
             which += f", but {args.batch} clips/GPU instead of {CLIPS_PER_GPU}"
+        inputs = "synthetic" if feeder is None else \
+            f"synthetic uint8 frames {args.input_hw} over PCIe every step + on-device clip transform (NOT the resident-input headline)"
         out = {
             "metric": f"clips/sec (fwd+bwd+step) {label} 16x112x112 bs={args.batch}/GPU",
             "value": round(value, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": inputs,
             "config": {"workload": f"{args.network} training step (zero_grad+fwd+MSE+bwd+Adam), {args.batch} clips/GPU "
                                    f"3x{FRAMES}x{SIZE}x{SIZE}, random-init, fp32 ({which})",
                        "clips_per_gpu": args.batch, "global_batch": world * args.batch,
@@ -314,48 +575,50 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "launcher": "self (one child process per GPU)" if os.environ.get("ZSV_BENCH_CHILD") else
                                    ("torch.distributed.run" if world > 1 else "single process"),
+                       "input": args.input,
                        "final_loss": float(loss.item()) if loss is not None else None},
+            # host side of a step: time until its last launch is queued.  `in_timed_region` includes any back-pressure of a
+            # full HIP queue (the host runs ahead of the GPU); `idle_queue` is one step queued right after a device sync.
+            "host_enqueue_ms": {"idle_queue": round(host_enqueue_ms, 3),
+                                "in_timed_region": round(1e3 * t_queued / args.steps, 3),
+                                "frac_of_step": round(host_enqueue_ms / ms_per_step, 3),
+                                "cores_of_this_rank": len(cores) if cores else usable_cores()},
         }
+        if feeder is not None:
+            out["config"]["pcie_bytes_per_step"] = int(feeder.bytes_per_step)
+            out["config"]["input_pipeline"] = ("pinned uint8 (N,T,H,W,3) -> hipMemcpyAsync on a copy stream, two slots -> "
+                                               "zsv_clip_transform (auxiliary/transforms.py:41-56) -> model")
         if sync is not None:
             out["config"]["allreduce_bytes_per_step"] = int(sync.bytes_reduced_last_step)
             out["config"]["allreduce_buckets"] = len(sync.bucket_sizes)
         # whole-step fractions of the two rooflines SURVEY section 8d defines
         per_gpu = value / world
         if args.network.startswith("r2plus1d"):
-            out["step_roofline"] = {"fp32_flop_frac": round(per_gpu * 242.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+            out["step_roofline"] = {"fp32_flop_frac_algorithmic": round(per_gpu * 242.5e9 / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
                                     "hbm_frac_unfused_bytes": round(per_gpu * 5.03e9 / 8.0e12, 4)}
         if timer is not None and timer.pairs:
-            ms = timer.durations_ms()
-            mean_ms = sum(ms) / len(ms)
-            n = args.batch
-            gm = dom["geometry"]
-            taps = gm["kT"] * gm["kH"] * gm["kW"]
-            voxels = gm["Ti"] * gm["Hi"] * gm["Wi"]                 # stride 1, "same" padding: output voxels = input voxels
-            flops = 2.0 * n * gm["Cout"] * gm["Cin"] * taps * voxels   # direct-convolution count (S1: 8.324 GFLOP/clip)
-            alg_bytes = 4.0 * (n * gm["Cin"] * voxels + n * gm["Cout"] * voxels + gm["Cout"] * gm["Cin"] * taps)
-            achieved = flops / (mean_ms * 1e-3) / 1e12
-            # the kernel computes the kw taps in Winograd F(4,3) form (W % 4 == 0): 6 multiplies per 4 outputs instead of
-            # 12, so the matrix pipe executes 1/2 of the algorithmic FLOPs (counter-checked: profiles/*_mfma_busy.json)
-            executed = flops * 0.5 / (mean_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": f"{dom['symbol']} = {dom['what']} "
-                                         f"(fp32 Winograd F(4,3) along W + its weight-transform launch), {dom['launches']} launch(es)/step",
-                               "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "achieved_is": "ALGORITHMIC (direct-convolution) FLOPs / time, as SURVEY 8d counts them; this is not "
-                                              "pipe utilisation: the Winograd form executes 1/2 of them -> mfma_executed_frac",
-                               "mfma_executed_tflops": round(executed, 2),
-                               "mfma_executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-                               "launches_timed": len(ms), "mean_launch_ms": round(mean_ms, 4),
-                               "algorithmic_gb_per_s": round(alg_bytes / (mean_ms * 1e-3) / 1e9, 1),
-                               "traffic": pmc_traffic(n) if args.network == "r2plus1d_18" else None}
+            out["roofline"] = roofline_entry(dom, args.batch, timer.durations_ms())
         if phases is not None:
             out["phases"] = phases
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.network, args.cpu_steps)
+        if world == 1 and not args.no_extras and args.network == "r2plus1d_18" and feeder is None:
+            del model, optimizer, x
+            torch.cuda.empty_cache()
+            extra = {}
+            for name, fn in (("c3d", extra_c3d), ("eval_t32_bf16", extra_eval_t32_bf16)):
+                try:
+                    log(f"extra.{name} ...")
+                    extra[name] = fn(dev)
+                except Exception as e:                      # the headline line must not be lost to a secondary leg
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
 
 
 if __name__ == "__main__":

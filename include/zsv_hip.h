@@ -49,6 +49,10 @@ typedef struct zsv_conv_desc {
 const char* zsv_status_string(int status);
 /* build identification: "zsv_hip gfx950 <date>" */
 const char* zsv_version(void);
+/* The ZSV_* debug / A-B environment switches are snapshotted when the library is loaded; the launch
+ * path never calls getenv().  After changing one of them in a live process call this (no launch in flight on another
+ * thread); returns the number of switches that are set.  Not needed in normal use. */
+int32_t zsv_reload_knobs(void);
 
 /* ---- convolution (aten::conv3d and its autograd formulas) ------------------- */
 /* y = conv3d(x, w) (+ bias[c]) (relu optional, for network.py:147-162 `relu(conv(x))`).

@@ -26,3 +26,34 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# The library snapshots its ZSV_* switches (csrc/knobs.h); `_lib.load()` refreshes the snapshot after an os.environ write.
+# Tests that hold on to the ctypes handle and call the raw C ABI after `monkeypatch.setenv("ZSV_...")` never pass through
+# `load()` again, so the two monkeypatch methods do it for them, and every test starts from a fresh snapshot.
+def _refresh_knobs():
+    try:
+        from zeroshotvideoclassification_amd import _lib
+        if os.path.isfile(_lib.LIB_PATH):
+            _lib.load()
+    except Exception:
+        pass
+
+
+def _wrap(method):
+    def inner(self, name, *args, **kwargs):
+        out = method(self, name, *args, **kwargs)
+        if str(name).startswith("ZSV_"):
+            _refresh_knobs()
+        return out
+    return inner
+
+
+pytest.MonkeyPatch.setenv = _wrap(pytest.MonkeyPatch.setenv)
+pytest.MonkeyPatch.delenv = _wrap(pytest.MonkeyPatch.delenv)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_knob_snapshot():
+    _refresh_knobs()
+    yield

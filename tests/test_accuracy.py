@@ -171,3 +171,69 @@ def test_sharded_evaluate_two_ranks_equals_single_process(tmp_path):
         assert res["n"] == n_kept
         for k, v in expected.items():
             assert res[k] == v, (rank, k, res[k], v)
+
+
+class _ShiftNet(torch.nn.Module):
+    """A stand-in model with BatchNorm running statistics (eval mode reads them): pred = bn(x)."""
+
+    def __init__(self, shift: float):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(300, affine=False)
+        with torch.no_grad():
+            self.bn.running_mean.copy_(torch.linspace(-1.0, 1.0, 300) * shift)
+            self.bn.running_var.fill_(1.0 + shift)
+
+    def forward(self, x):
+        return self.bn(x), None
+
+
+def _sharded_bn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import json
+    import torch.distributed as dist
+    from zeroshotvideoclassification_amd import train
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        table, labels, true, pred = synthetic.synthetic_eval_set(400, 51, seed=5, noise=0.45)
+        # after data-parallel training every replica holds ITS OWN running statistics (ddp.GradientSync keeps them per rank)
+        model = _ShiftNet(0.0 if rank == 0 else 3.0).to(dev)
+        batches = _batches(pred, labels, true, 50)
+        res = train.evaluate(model, batches, table, device=dev)
+        synced_mean = model.bn.running_mean.abs().max().item()
+        # a per-rank loader: this rank's own shard, nothing skipped
+        mine = [b for i, b in enumerate(batches) if i % world == rank]
+        res_local = train.evaluate(model, mine, table, device=dev, local_batches=True)
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+            json.dump({"res": res, "local": res_local, "mean": synced_mean}, f)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_evaluate_scores_every_sample_with_rank0_statistics(tmp_path):
+    """Replicas whose BatchNorm running statistics differ (the state data-parallel training leaves behind): a sharded
+    evaluate must score ALL samples with rank 0's model -- what nn.DataParallel does (device 0's buffers, main.py:126,250)
+    and what rank 0 checkpoints -- not a mix of `world` models."""
+    import json
+    import torch.multiprocessing as mp
+    from zeroshotvideoclassification_amd import train
+    mp.spawn(_sharded_bn_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    dev = torch.device("cuda", 0)
+    table, labels, true, pred = synthetic.synthetic_eval_set(400, 51, seed=5, noise=0.45)
+    want = train.evaluate(_ShiftNet(0.0).to(dev), _batches(pred, labels, true, 50), table, device=dev, sharded=False)
+    mixed = train.evaluate(_ShiftNet(3.0).to(dev), _batches(pred, labels, true, 50), table, device=dev, sharded=False)
+    assert mixed["accuracy"] != want["accuracy"]                     # the statistics matter: the test has teeth
+    for rank in range(2):
+        with open(tmp_path / f"rank{rank}.json") as f:
+            got = json.load(f)
+        assert got["mean"] == 0.0                                      # rank 1 now holds rank 0's buffers
+        for key in ("res", "local"):
+            for k, v in want.items():
+                assert got[key][k] == v, (rank, key, k, got[key][k], v)

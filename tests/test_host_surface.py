@@ -204,3 +204,35 @@ def test_bench_self_launch_builds_one_child_per_gpu():
     assert r.returncode != 0 and "HIP device(s) are visible" in r.stderr and "clips/s" not in r.stdout
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os.exec" not in src and "execv" not in src                # children are started, never exec'ed into
+
+
+def test_environment_switches_are_snapshotted_and_reloaded():
+    """The library reads its ZSV_* switches once (csrc/knobs.h), not with getenv() on every launch; flipping one through
+    os.environ in a live process is noticed by _lib's audit hook and re-read before the next call."""
+    from ctypes import byref
+    from zeroshotvideoclassification_amd import _lib, ops
+    d = ops.conv_desc((2, 64, 8, 56, 56), (144, 64, 1, 3, 3), 1, (0, 1, 1))
+    saved = os.environ.pop("ZSV_NO_WINO", None)
+    try:
+        lib = _lib.load()
+        base = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+        os.environ["ZSV_NO_WINO"] = "1"
+        assert _lib._knobs_dirty
+        assert lib.zsv_conv3d_fwd_workspace_bytes(byref(d)) == base          # the snapshot, not the environment, decides
+        lib = _lib.load()                                   # every op passes through load(): the snapshot is refreshed here
+        assert not _lib._knobs_dirty
+        direct = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+        assert direct != base                               # the Winograd-form kernel and the direct kernel pack weights differently
+        del os.environ["ZSV_NO_WINO"]
+        assert _lib.load().zsv_conv3d_fwd_workspace_bytes(byref(d)) == base
+        os.environ["UNRELATED_VARIABLE"] = "1"
+        assert not _lib._knobs_dirty
+        del os.environ["UNRELATED_VARIABLE"]
+    finally:
+        os.environ.pop("ZSV_NO_WINO", None)
+        if saved is not None:
+            os.environ["ZSV_NO_WINO"] = saved
+        _lib.load()
+    csrc = os.path.join(ROOT, "zeroshotvideoclassification_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip") and f != "knobs.hip")
+    assert "getenv(" not in src                         # the launch path never walks the environment

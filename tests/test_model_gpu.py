@@ -593,3 +593,39 @@ def test_gradient_accumulation_with_the_wgrad_side_stream():
             ref = once[k] * 2
             err = (p.grad - ref).abs().max().item()
             assert err <= 1e-5 * (ref.abs().max().item() + 1e-12), (k, err)
+
+
+def test_shared_weights_in_one_graph_with_the_wgrad_side_stream(monkeypatch):
+    """One weight, two gradients inside ONE backward pass (the model applied to two clip batches before backward: siamese /
+    multi-clip forwards, tied weights): autograd sums dw1 + dw2 on the backward stream as soon as the second arrives, so that
+    stream has to wait for the side stream still writing them.  Also with a tensor hook on a weight (runs on dw right away).
+    Must equal the single-stream run bit for bit."""
+    g, model, weights = build("r2plus1d_small")
+    x, z = case_inputs(g)
+    xd, zd = x.to(DEV), z.to(DEV)
+    xd2 = (xd * 0.5 - 0.1).contiguous()
+    hooked = model.model.layer1[0].conv1[0][0].weight
+    seen = []
+
+    def grads():
+        model.load_state_dict(weights)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        seen.clear()
+        h = hooked.register_hook(lambda gw: seen.append(gw.abs().sum().clone()))       # reads dw on the backward stream
+        try:
+            loss = F.mse_loss(train.embed(model, xd), zd) + 0.5 * F.mse_loss(train.embed(model, xd2), zd)
+            loss.backward()
+        finally:
+            h.remove()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, seen[0].item()
+
+    monkeypatch.setenv("ZSV_WGRAD_STREAM", "0")
+    ref, ref_hook = grads()
+    monkeypatch.setenv("ZSV_WGRAD_STREAM", "1")
+    for _ in range(3):
+        got, got_hook = grads()
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+        assert got_hook == ref_hook

@@ -1066,3 +1066,34 @@ def test_conv3d_r2plus1d_family_fuzz():
         yg.backward(dy.to(DEV))
         close(xg.grad, xr.grad, rtol=3e-5, what=tag + " dgrad")
         close(wg.grad, wr.grad, rtol=5e-5, what=tag + " wgrad")
+
+
+@pytest.mark.parametrize("offset", [0, 1, 3])
+def test_relu_bwd_bias_on_misaligned_views(offset):
+    """zsv_relu_bwd_bias (C3D's relu(conv + b) backward: ReLU mask and bias gradient in one pass): its float4 path needs
+    16-byte aligned bases -- a contiguous view that starts at an odd element of a larger buffer must take the scalar path."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    lib = _lib.load()
+    n, c, s = 3, 5, 64
+    g = torch.Generator().manual_seed(offset)
+
+    def view(t):
+        buf = torch.zeros(t.numel() + 8, device=DEV)
+        v = buf[offset:offset + t.numel()].view(t.shape)
+        v.copy_(t)
+        return v
+
+    dy, y = torch.randn(n, c, s, generator=g), torch.randn(n, c, s, generator=g)
+    dyd, yd = view(dy), view(y)
+    gd = view(torch.zeros(n, c, s))
+    assert dyd.is_contiguous() and (dyd.data_ptr() % 16 == 0) == (offset == 0)
+    db = torch.empty(c, device=DEV)
+    nb = lib.zsv_channel_sum_workspace_bytes(n, c, s)
+    ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.zsv_relu_bwd_bias(dyd.data_ptr(), yd.data_ptr(), gd.data_ptr(), n, c, s, db.data_ptr(), ws.data_ptr(), nb, None),
+               "zsv_relu_bwd_bias")
+    torch.cuda.synchronize()
+    ref = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(gd.cpu(), ref)
+    close(db, ref.double().sum(dim=(0, 2)), what="bias gradient")

@@ -123,3 +123,74 @@ def test_fused_adam_walks_the_gradient_buckets(use_scaler):
         ref_opt.step()
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             assert (p - q).abs().max().item() <= 1e-5 * (q.abs().max().item() + 1e-6), ("reloaded", k)
+
+
+def test_inf_in_a_later_group_skips_every_group():
+    """GradScaler.step checks all gradients before the optimizer updates anything: with two parameter groups and a
+    non-finite gradient only in the SECOND, the first group must stay untouched as well (then both step normally)."""
+    pa, pb = _params(11, DEV), _params(12, DEV)
+    before = [p.detach().clone() for p in pa + pb]
+    opt = optim.FusedAdam([{"params": pa}, {"params": pb, "lr": 3e-3}], lr=1e-2)
+    scaler = optim.LossScaler(init_scale=64.0)
+    ref_a, ref_b = [p.detach().clone().requires_grad_() for p in pa], [p.detach().clone().requires_grad_() for p in pb]
+    ref_opt = torch.optim.Adam([{"params": ref_a}, {"params": ref_b, "lr": 3e-3}], lr=1e-2)
+    ref_scaler = torch.amp.GradScaler("cuda", init_scale=64.0)
+    for step, poison in enumerate([float("inf"), None, None]):
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(_loss(pa, step, None) + _loss(pb, 50 + step, poison)).backward()
+        scaler.step(opt)
+        scaler.update()
+        ref_opt.zero_grad(set_to_none=True)
+        ref_scaler.scale(_loss(ref_a, step, None) + _loss(ref_b, 50 + step, poison)).backward()
+        ref_scaler.step(ref_opt)
+        ref_scaler.update()
+        if step == 0:
+            for p, q in zip(pa + pb, before):
+                assert torch.equal(p.detach(), q)                    # nothing moved, in either group
+        for a, b in zip(pa + pb, ref_a + ref_b):
+            assert (a.detach() - b.detach()).abs().max().item() <= 2e-6 * b.detach().abs().max().item()
+    assert scaler.state()["steps_done"] == 2 and scaler.get_scale() == ref_scaler.get_scale()
+
+
+def test_resume_under_the_loss_scaler():
+    """Checkpoint / resume of the scaled optimizer: LossScaler.state_dict() / load_state_dict() carry scale, growth tracker
+    and the count of steps taken; a FusedAdam restored with load_state_dict() accepts the scaler afterwards and continues the
+    trajectory of an uninterrupted run."""
+    def run(split_at):
+        ps = _params(21, DEV)
+        opt = optim.FusedAdam(ps, lr=1e-2)
+        scaler = optim.LossScaler(init_scale=512.0, growth_interval=2)
+        for step in range(6):
+            if step == split_at:
+                sd_o, sd_s = copy.deepcopy(opt.state_dict()), scaler.state_dict()
+                opt = optim.FusedAdam(ps, lr=1e-2)
+                opt.load_state_dict(sd_o)
+                scaler = optim.LossScaler(init_scale=1.0)
+                scaler.load_state_dict(sd_s)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(_loss(ps, step, float("nan") if step == 1 else None)).backward()
+            scaler.step(opt)
+            scaler.update()
+        return [p.detach().clone() for p in ps], scaler.state_dict()
+
+    straight, s0 = run(None)
+    resumed, s1 = run(3)
+    assert s0 == s1 and s0["steps_done"] == 5 and set(s0) >= {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    for a, b in zip(straight, resumed):
+        assert torch.equal(a, b)
+    # a torch GradScaler state dict (no steps_done) is accepted: the optimizer's loaded step count seeds the scaler
+    ps = _params(21, DEV)
+    opt = optim.FusedAdam(ps, lr=1e-2)
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        _loss(ps, step, None).backward()
+        opt.step()
+    opt2 = optim.FusedAdam(ps, lr=1e-2)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    scaler = optim.LossScaler()
+    scaler.load_state_dict(torch.amp.GradScaler("cuda", init_scale=128.0).state_dict())
+    opt2.zero_grad(set_to_none=True)
+    scaler.scale(_loss(ps, 2, None)).backward()
+    scaler.step(opt2)
+    scaler.update()
+    assert scaler.state()["steps_done"] == 3 and scaler.get_scale() == 128.0

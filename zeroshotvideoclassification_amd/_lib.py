@@ -28,6 +28,7 @@ _P = c_void_p
 SIGNATURES = {
     "zsv_status_string": (c_char_p, [c_int]),
     "zsv_version": (c_char_p, []),
+    "zsv_reload_knobs": (c_int32, []),
     "zsv_conv3d_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "zsv_conv3d_fwd_stat_tiles": (c_int32, [POINTER(ConvDesc), _P]),
@@ -93,10 +94,26 @@ _lock = threading.Lock()
 _lib = None
 
 
+# The library snapshots its ZSV_* switches at load (csrc/knobs.h).  Tests and A/B tools flip them with os.environ inside
+# a live process: an audit hook notices such a write and the next ``load()`` -- every op goes through it -- re-reads them.
+_knobs_dirty = False
+
+
+def _watch_environment(event, args):
+    global _knobs_dirty
+    if event in ("os.putenv", "os.unsetenv") and args and bytes(args[0]).startswith(b"ZSV_"):
+        _knobs_dirty = True
+
+
 def load() -> ctypes.CDLL:
     """Load (once) and type the library; raises ``RuntimeError`` when it has not been built."""
-    global _lib
+    global _lib, _knobs_dirty
     if _lib is not None:
+        if _knobs_dirty:
+            with _lock:
+                if _knobs_dirty:
+                    _knobs_dirty = False
+                    _lib.zsv_reload_knobs()
         return _lib
     with _lock:
         if _lib is None:
@@ -110,6 +127,9 @@ def load() -> ctypes.CDLL:
                 fn = getattr(lib, name)      # AttributeError if the symbol is not exported
                 fn.restype = res
                 fn.argtypes = args
+            import sys
+            sys.addaudithook(_watch_environment)
+            _knobs_dirty = False
             _lib = lib
     return _lib
 

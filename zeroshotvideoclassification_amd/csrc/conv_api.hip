@@ -7,6 +7,7 @@
 //   * conv_igemm.hip (generic (channel, tap) order) otherwise (3-channel stems, 7x7 kernels).
 #include <stdlib.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 using namespace zsv;
 
@@ -97,7 +98,7 @@ extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
 
 extern "C" int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y) {
     if (conv_check(d) != ZSV_OK) return 0;
-    if (wino_fwd_applicable(d)) return (getenv("ZSV_NO_FUSED_STATS") || !wino_fwd_fusable(d)) ? 0 : wino_fwd_stat_tiles(d);
+    if (wino_fwd_applicable(d)) return (ZSV_KNOB(NO_FUSED_STATS) || !wino_fwd_fusable(d)) ? 0 : wino_fwd_stat_tiles(d);
     IgemmParams p;
     fwd_params(p, d, 0);
     return igemm_tap_stat_tiles(p, y);
@@ -174,7 +175,7 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
 // (Conv2Plus1D's `BatchNorm3d(mid) -> ReLU -> temporal conv`, resnet.py:46-52): both the forward (direct kernel, PRE form)
 // and the weight gradient (frame-ring kernel, PRE form) must be able to apply the affine + ReLU while they read x.
 extern "C" int32_t zsv_conv3d_pre_supported(const zsv_conv_desc* d) {
-    if (conv_check(d) != ZSV_OK || getenv("ZSV_NO_BN_FUSION") || !wgrad_tring_applicable(d, nullptr, nullptr)) return 0;
+    if (conv_check(d) != ZSV_OK || ZSV_KNOB(NO_BN_FUSION) || !wgrad_tring_applicable(d, nullptr, nullptr)) return 0;
     if (wino_fwd_applicable(d)) return wino_fwd_pre_capable(d) ? 1 : 0;          // (the temporal F(2,3)-along-T kernel)
     IgemmParams p;
     fwd_params(p, d, 0);

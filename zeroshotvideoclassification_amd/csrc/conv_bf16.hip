@@ -28,6 +28,7 @@
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -770,7 +771,7 @@ static int bf16_same_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, 
 // stride 1, output extents = input extents, kW = 3 with pW = 1: taps are flattened shifts
 static bool bf16_same_applicable(const zsv_conv_desc* d) {
     return !bf16_folded(d) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->kW == 3 && d->pW == 1 && d->To == d->Ti &&
-           d->Ho == d->Hi && d->Wo == d->Wi && getenv("ZSV_BF16_NO_SAME") == nullptr;
+           d->Ho == d->Hi && d->Wo == d->Wi && ZSV_KNOB(BF16_NO_SAME) == nullptr;
 }
 
 template <int TM, int TT>
@@ -791,7 +792,7 @@ static int bf16_tsame_launch(Bf16Params& p, const zsv_conv_desc* d, hipStream_t 
 // 3x1x1, stride 1, pad (1,0,0): frames-x-positions tiles if the clip divides into them; returns TT or 0
 static int bf16_tsame_frames(const zsv_conv_desc* d) {
     if (bf16_folded(d) || d->kT != 3 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 1 ||
-        d->pH != 0 || d->pW != 0 || getenv("ZSV_BF16_NO_TSAME"))
+        d->pH != 0 || d->pW != 0 || ZSV_KNOB(BF16_NO_TSAME))
         return 0;
     const int HW = d->Hi * d->Wi;
     if (d->Ti % 8 == 0 && HW % 32 == 0) return 8;

@@ -22,6 +22,7 @@
 //   * small problems (layer4: 4 k voxels) cut the K range into parts whose slabs splitk_reduce() adds in fixed order.
 #include <stdlib.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -273,8 +274,8 @@ struct S2Plan { int kind, bn, ks, tiles_m, tiles_n, nchunks, cps; };
 
 static bool s2_plan(const zsv_conv_desc* d, S2Plan& pl) {
     pl.kind = s2_kind(d);
-    if (pl.kind < 0 || getenv("ZSV_NO_DGRAD_S2")) return false;
-    if (pl.kind == KIND_T && getenv("ZSV_NO_DGRAD_S2T")) return false;
+    if (pl.kind < 0 || ZSV_KNOB(NO_DGRAD_S2)) return false;
+    if (pl.kind == KIND_T && ZSV_KNOB(NO_DGRAD_S2T)) return false;
     if (d->Cout < 8 || d->Cin < 16 || d->Wo + 1 > 128) return false;
     const long P = (long)d->N * d->To * d->Ho * d->Wo;
     // byte offsets live in 32-bit registers, the sentinel 0xFFFFFFFF must stay out of range: tensors below 2^29 elements
@@ -282,7 +283,7 @@ static bool s2_plan(const zsv_conv_desc* d, S2Plan& pl) {
     pl.tiles_m = (d->Cin + 63) / 64;
     pl.nchunks = (d->Cout + 7) / 8;
     const long t128 = pl.tiles_m * ((P + 127) / 128);
-    const char* e = getenv("ZSV_DGRAD_S2_BN");
+    const char* e = ZSV_KNOB(DGRAD_S2_BN);
     pl.bn = e ? atoi(e) : (t128 >= 1536 ? 128 : 64);
     if (pl.bn != 64 && pl.bn != 128) return false;
     pl.tiles_n = (int)((P + pl.bn - 1) / pl.bn);
@@ -295,7 +296,7 @@ static bool s2_plan(const zsv_conv_desc* d, S2Plan& pl) {
         if (ks > 8) ks = 8;
         if (ks < 1) ks = 1;
     }
-    if (const char* k = getenv("ZSV_DGRAD_S2_KS")) ks = atol(k) < 1 ? 1 : atol(k);
+    if (const char* k = ZSV_KNOB(DGRAD_S2_KS)) ks = atol(k) < 1 ? 1 : atol(k);
     pl.ks = (int)ks;
     pl.cps = (pl.nchunks + pl.ks - 1) / pl.ks;
     pl.ks = (pl.nchunks + pl.cps - 1) / pl.cps;          // no empty part
@@ -339,7 +340,7 @@ static int s2_launch_x(bool x4, const DgradS2Params& p, const float* wp, const f
 // dx += zero-insertion of `sub` (the gradient of a 1x1x1 convolution of stride (sub_st, 2, 2) on the same input) -- spatial form only
 bool dgrad_s2_sub_supported(const zsv_conv_desc* d, int st, int sh, int sw) {
     S2Plan pl;
-    return s2_plan(d, pl) && pl.kind == KIND_HW && sh == 2 && sw == 2 && (st == 1 || st == 2) && getenv("ZSV_NO_DOWN_FUSION") == nullptr;
+    return s2_plan(d, pl) && pl.kind == KIND_HW && sh == 2 && sw == 2 && (st == 1 || st == 2) && ZSV_KNOB(NO_DOWN_FUSION) == nullptr;
 }
 
 int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int sub_st, float* dx, void* workspace,
@@ -359,7 +360,7 @@ int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, const floa
     p.nimg = pl.kind == KIND_T ? 2 * pl.bn : pl.bn + d->Wo + 1;
     p.nseg = (p.nimg + 63) / 64;
     const bool x4 = p.S % 4 == 0 && (pl.kind == KIND_HW || p.HW % 4 == 0) && p.nimg <= 256 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
-                    getenv("ZSV_DGRAD_S2_NO_X4") == nullptr;
+                    ZSV_KNOB(DGRAD_S2_NO_X4) == nullptr;
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.S);
     p.ksplit = pl.ks; p.chunks_per_split = pl.cps;
     p.slab_elems = (int)((long)d->N * d->Cin * p.oS);

@@ -37,6 +37,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -293,7 +294,7 @@ static int dispatch(const IgemmParams& prm, const float* A, const float* G, cons
         if (blocks < 512) w *= (512.0 / (blocks < 1 ? 1 : blocks)) > 4.0 ? 4.0 : (512.0 / blocks);
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
-    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e);     // tuning override (tools/conv_bench.py)
+    if (const char* e = ZSV_KNOB(CONV_CFG)) best = atoi(e);     // tuning override (tools/conv_bench.py)
     switch (best) {
         case 0: return launch_cfg<9, 2, 1, 4, AVEC, WIDE>(prm, A, G, bias, C, stream);
         case 1: return launch_cfg<4, 4, 2, 2, AVEC, WIDE>(prm, A, G, bias, C, stream);

@@ -29,6 +29,7 @@
 // 3-channel 7x7 stems stay on conv_igemm.hip.
 #include <stdlib.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -338,9 +339,9 @@ static const int kNumTapCfgs = 6;
 static long tap_ksplit_for(long tiles, long nchunks) {
     // 1024 workgroups are resident at once (256 CUs x 4); split K when one round is under-filled
     long thresh = 700, target = 1024;
-    if (getenv("ZSV_NO_SPLITK")) return 1;
-    if (const char* e = getenv("ZSV_TAP_KS")) return atol(e) < 1 ? 1 : (atol(e) > nchunks ? nchunks : atol(e));      // (sweeps)
-    if (const char* e = getenv("ZSV_SPLITK_THRESH")) thresh = atol(e);
+    if (ZSV_KNOB(NO_SPLITK)) return 1;
+    if (const char* e = ZSV_KNOB(TAP_KS)) return atol(e) < 1 ? 1 : (atol(e) > nchunks ? nchunks : atol(e));      // (sweeps)
+    if (const char* e = ZSV_KNOB(SPLITK_THRESH)) thresh = atol(e);
     if (tiles >= thresh || nchunks < 32) return 1;
     long ks = (target + tiles / 2) / tiles;              // nearest whole multiple of the tile count
     if (ks > nchunks / 12) ks = nchunks / 12;            // >= 12 chunks per part
@@ -366,7 +367,7 @@ static int tap_pick(const IgemmParams& prm) {
     for (int i = 0; i < kNumTapCfgs; ++i) {
         // 64x256 only where one row tile covers the problem (M <= 64, the 1.1 M-voxel layer1 / stem
         // launches): on wider outputs the sweep found it better on some mid-size layers and worse on as many
-        if (i == 5 && (prm.M > 64 || getenv("ZSV_NO_CFG5"))) continue;
+        if (i == 5 && (prm.M > 64 || ZSV_KNOB(NO_CFG5))) continue;
         const long tm = (prm.M + kTapCfgs[i].bm - 1) / kTapCfgs[i].bm;
         const long tn = ((long)prm.P + kTapCfgs[i].bn - 1) / kTapCfgs[i].bn;
         const double tiles = (double)(tm * tn);
@@ -380,12 +381,12 @@ static int tap_pick(const IgemmParams& prm) {
         }
         if (w < best_w * 0.999) { best_w = w; best = i; }
     }
-    if (const char* e = getenv("ZSV_CONV_CFG")) best = atoi(e) % kNumTapCfgs;
+    if (const char* e = ZSV_KNOB(CONV_CFG)) best = atoi(e) % kNumTapCfgs;
     return best;
 }
 
 bool igemm_tap_applicable(const IgemmParams& prm) {
-    if (getenv("ZSV_NO_TAP")) return false;
+    if (ZSV_KNOB(NO_TAP)) return false;
     return prm.gC >= 16 && prm.taps <= 31 && prm.K > 0;
 }
 
@@ -428,11 +429,11 @@ static int tap_launch(const IgemmParams& prm, const float* Wp, const float* G, c
 
 static bool tap_lds_epilogue_ok(const IgemmParams& prm, const float* C) {
     return prm.stW == 1 && prm.stH == 1 && prm.stT == 1 && prm.oS % 4 == 0 && prm.cS == prm.oS &&
-           (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !getenv("ZSV_NO_LDS_EPILOGUE");
+           (reinterpret_cast<uintptr_t>(C) & 15) == 0 && !ZSV_KNOB(NO_LDS_EPILOGUE);
 }
 
 int igemm_tap_stat_tiles(const IgemmParams& prm, const float* C) {
-    if (!igemm_tap_applicable(prm) || !tap_lds_epilogue_ok(prm, C) || getenv("ZSV_NO_FUSED_STATS")) return 0;
+    if (!igemm_tap_applicable(prm) || !tap_lds_epilogue_ok(prm, C) || ZSV_KNOB(NO_FUSED_STATS)) return 0;
     if (igemm_tap_ksplit(prm) > 1) return 0;
     int cfg, tiles_m, Mp, nblk, Cpad;
     tap_layout(prm, cfg, tiles_m, Mp, nblk, Cpad);

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -408,18 +409,18 @@ static WgradPlan wgrad_plan(const zsv_conv_desc* d) {
             const double w = (double)(tm * bms[i]) * (double)(tn * bns[j]) * pen_m[i] * pen_n[j] / (eff > 1e-3 ? eff : 1e-3);
             if (w < best_w * 0.999) { best_w = w; best_m = i; best_n = j; }
         }
-    if (const char* e = getenv("ZSV_WGRAD_CFG")) best_m = atoi(e) & 3;
+    if (const char* e = ZSV_KNOB(WGRAD_CFG)) best_m = atoi(e) & 3;
     pl.cfg = best_m;
     pl.bm = bms[best_m];
     pl.bn = bns[best_n];
-    if (const char* e = getenv("ZSV_WGRAD_BN")) pl.bn = atoi(e) == 64 ? 64 : 128;
+    if (const char* e = ZSV_KNOB(WGRAD_BN)) pl.bn = atoi(e) == 64 ? 64 : 128;
     pl.tiles_m = (M + pl.bm - 1) / pl.bm;
     pl.tiles_n = (pl.Kp + pl.bn - 1) / pl.bn;
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     long slices;
     wgrad_slices(tiles, chunks, bp, pl.bm, pl.bn, slices);
     const long max_slices = ((chunks * bp + 511) / 512) < 1 ? 1 : ((chunks * bp + 511) / 512 > 1024 ? 1024 : (chunks * bp + 511) / 512);
-    if (const char* e = getenv("ZSV_WGRAD_WGS")) slices = atol(e) / tiles;
+    if (const char* e = ZSV_KNOB(WGRAD_WGS)) slices = atol(e) / tiles;
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
     pl.chunks_per_slice = (int)((chunks + slices - 1) / slices);
@@ -522,7 +523,7 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     p.dy_bytes = 4u * (unsigned)((long)d->N * d->Cout * p.oS);
 
     const bool av4 = (p.oS % 4 == 0) && (p.P >= 4) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
-    const bool twotap = wgrad_two_taps(p.taps, pl.nblk, pl.bn) && !getenv("ZSV_WGRAD_NO_TWOTAP");
+    const bool twotap = wgrad_two_taps(p.taps, pl.nblk, pl.bn) && !ZSV_KNOB(WGRAD_NO_TWOTAP);
     const int tiles_mn = pl.tiles_m * pl.tiles_n;
     const dim3 grid((unsigned)(tiles_mn * pl.slices));
     float* out = (float*)workspace;

@@ -25,6 +25,7 @@
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256, (TM * TN > 27 ? 2 : 3)) void conv_wgrad_dma_ke
 
 // ---- host side -----------------------------------------------------------------------------------
 bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* dy) {
-    if (getenv("ZSV_NO_WGRAD_DMA")) return false;
+    if (ZSV_KNOB(NO_WGRAD_DMA)) return false;
     if (d->Cin < 16 || d->Cout < 16) return false;
     if (d->sT != 1 || d->sH != 1 || d->sW != 1) return false;
     if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi) return false;
@@ -348,12 +349,12 @@ static WgradDmaPlan wgrad_dma_plan(const zsv_conv_desc* d) {
             const double w = (double)(tm_ * bm) * (double)(tn_ * bn) * pen_m[i] * pen_n[j] / (best_eff > 1e-3 ? best_eff : 1e-3);
             if (w < best_w * 0.999) { best_w = w; pl.tm = tms[i]; pl.tn = tns[j]; pl.slices = (int)sl; }
         }
-    if (const char* e = getenv("ZSV_WGRAD_DMA_TM")) { const int t = atoi(e); if (t == 9 || t == 8 || t == 4 || t == 5) pl.tm = t; }
-    if (const char* e = getenv("ZSV_WGRAD_DMA_TN")) { const int t = atoi(e); if ((t >= 1 && t <= 3 && t * pl.tm <= 27) || (t == 7 && pl.tm == 4)) pl.tn = t; }
+    if (const char* e = ZSV_KNOB(WGRAD_DMA_TM)) { const int t = atoi(e); if (t == 9 || t == 8 || t == 4 || t == 5) pl.tm = t; }
+    if (const char* e = ZSV_KNOB(WGRAD_DMA_TN)) { const int t = atoi(e); if ((t >= 1 && t <= 3 && t * pl.tm <= 27) || (t == 7 && pl.tm == 4)) pl.tn = t; }
     const int bm = 16 * pl.tm, bn = 64 * pl.tn;
     pl.tiles_m = (M + bm - 1) / bm;
     pl.tiles_n = (pl.Kp + bn - 1) / bn;
-    if (const char* e = getenv("ZSV_WGRAD_DMA_SLICES")) pl.slices = atoi(e);
+    if (const char* e = ZSV_KNOB(WGRAD_DMA_SLICES)) pl.slices = atoi(e);
     if (pl.slices > max_slices) pl.slices = (int)max_slices;
     if (pl.slices < 1) pl.slices = 1;
     pl.chunks_per_slice = (int)((chunks + pl.slices - 1) / pl.slices);
@@ -412,7 +413,7 @@ int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* wor
     p.S = d->Ti * d->Hi * d->Wi; p.HW = d->Hi * d->Wi; p.W = d->Wi;
     p.kH = d->kH; p.kW = d->kW; p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.chunks_total = (int)((long)d->N * p.S / 16);
-    p.walk_T = (d->kT > 1 && d->Ti > 1 && p.HW % 16 == 0 && getenv("ZSV_WGRAD_LINEAR_WALK") == nullptr) ? d->Ti : 0;
+    p.walk_T = (d->kT > 1 && d->Ti > 1 && p.HW % 16 == 0 && ZSV_KNOB(WGRAD_LINEAR_WALK) == nullptr) ? d->Ti : 0;
     p.chunks_per_slice = pl.chunks_per_slice;
     p.x_elems = (long)d->N * d->Cin * p.S;
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "conv_params.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemWgradParams prm, co
 }
 
 static bool stem_wgrad_shape(const zsv_conv_desc* d) {
-    if (getenv("ZSV_NO_STEM_WGRAD")) return false;
+    if (ZSV_KNOB(NO_STEM_WGRAD)) return false;
     if (d->Cin != 3 || d->kT != 1 || d->sT != 1 || d->pT != 0 || d->kH != 7 || d->kW != 7 || d->sH != 2 || d->sW != 2 || d->pH != 3 || d->pW != 3)
         return false;
     if (d->Hi % 2 != 0 || d->Wi % 4 != 0 || d->Wo != d->Wi / 2 || d->Ho != d->Hi / 2 || d->Wo % 4 != 0) return false;
@@ -360,7 +361,7 @@ static bool stem_wgrad_shape(const zsv_conv_desc* d) {
 static int stem_wgrad_parts(const zsv_conv_desc* d) {
     const long frames = (long)d->N * d->To;
     long target = 1408;
-    if (const char* e = getenv("ZSV_STEM_WGRAD_WGS")) target = atol(e) > 0 ? atol(e) : target;
+    if (const char* e = ZSV_KNOB(STEM_WGRAD_WGS)) target = atol(e) > 0 ? atol(e) : target;
     long parts = (target + frames - 1) / frames;
     const long maxp = (d->Ho + 7) / 8;
     if (parts > maxp) parts = maxp;

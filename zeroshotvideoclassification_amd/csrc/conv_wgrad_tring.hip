@@ -20,6 +20,7 @@
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -464,7 +465,7 @@ static WgradTringPlan wgrad_tring_plan(const zsv_conv_desc* d) {
     const long chunks = (long)d->N * d->Ti * (d->Hi * d->Wi / 16);
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     long resident = pl.tm == 9 ? 512 : 768;                // workgroups per round (3 fit a CU; measured: 2 per CU is the better fill for the 144-row tile)
-    if (const char* e = getenv("ZSV_WGRAD_TRING_RESIDENT")) resident = atol(e) > 0 ? atol(e) : resident;
+    if (const char* e = ZSV_KNOB(WGRAD_TRING_RESIDENT)) resident = atol(e) > 0 ? atol(e) : resident;
     // slices: MFMA time / fill of the rounds of resident workgroups + slab write / read, >= 32 chunks per slice
     const double t_mfma = 2.0 * (double)(pl.tiles_m * bm) * (double)(pl.tiles_n * 192) * (double)chunks * 16.0 / 1.1e14;
     const double t_slice = 2.0 * (double)C * 3.0 * d->Cout * sizeof(float) / 6.0e12;
@@ -478,7 +479,7 @@ static WgradTringPlan wgrad_tring_plan(const zsv_conv_desc* d) {
         const double cost = t_mfma * (double)(rounds * resident) / (double)wgs + t_slice * (double)c;
         if (cost < best * 0.999) { best = cost; sl = c; }
     }
-    if (const char* e = getenv("ZSV_WGRAD_TRING_SLICES")) sl = atol(e) > 0 ? atol(e) : 1;
+    if (const char* e = ZSV_KNOB(WGRAD_TRING_SLICES)) sl = atol(e) > 0 ? atol(e) : 1;
     if (sl > chunks) sl = chunks;
     pl.chunks_per_slice = (int)((chunks + sl - 1) / sl);
     pl.slices = (int)((chunks + pl.chunks_per_slice - 1) / pl.chunks_per_slice);
@@ -486,7 +487,7 @@ static WgradTringPlan wgrad_tring_plan(const zsv_conv_desc* d) {
 }
 
 bool wgrad_tring_applicable(const zsv_conv_desc* d, const float* x, const float* dy) {
-    if (getenv("ZSV_NO_WGRAD_TRING")) return false;
+    if (ZSV_KNOB(NO_WGRAD_TRING)) return false;
     if (d->kT != 3 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != 1 || d->pH != 0 || d->pW != 0)
         return false;
     if (d->Ti % 4 != 0 || (d->Hi * d->Wi) % 16 != 0) return false;     // ring slots f & 3; whole 16-position segments
@@ -503,7 +504,7 @@ bool wgrad_tring_applicable(const zsv_conv_desc* d, const float* x, const float*
 }
 
 // the Winograd form (conv_wgrad_twino_kernel): chunks are frame pairs, two workgroups per CU
-static bool wgrad_twino_shape(const zsv_conv_desc* d) { return d->Ti >= 8 && getenv("ZSV_NO_WGRAD_TWINO") == nullptr; }
+static bool wgrad_twino_shape(const zsv_conv_desc* d) { return d->Ti >= 8 && ZSV_KNOB(NO_WGRAD_TWINO) == nullptr; }
 static WgradTringPlan wgrad_twino_plan(const zsv_conv_desc* d) {
     WgradTringPlan pl;
     const int C = d->Cin;
@@ -515,7 +516,7 @@ static WgradTringPlan wgrad_twino_plan(const zsv_conv_desc* d) {
     const long chunks = (long)d->N * (d->Ti / 2) * (d->Hi * d->Wi / 16);
     const long tiles = (long)pl.tiles_m * pl.tiles_n;
     long resident = 512;
-    if (const char* e = getenv("ZSV_WGRAD_TRING_RESIDENT")) resident = atol(e) > 0 ? atol(e) : resident;
+    if (const char* e = ZSV_KNOB(WGRAD_TRING_RESIDENT)) resident = atol(e) > 0 ? atol(e) : resident;
     // slices: MFMA time / fill of the rounds of resident workgroups + slab write / read, >= 16 chunks per slice
     const double t_mfma = 2.0 * (double)(pl.tiles_m * bm) * (double)(pl.tiles_n * 256) * (double)chunks * 16.0 / 1.1e14;
     const double t_slice = 2.0 * (double)C * 4.0 * d->Cout * sizeof(float) / 6.0e12;
@@ -529,7 +530,7 @@ static WgradTringPlan wgrad_twino_plan(const zsv_conv_desc* d) {
         const double cost = t_mfma * (double)(rounds * resident) / (double)wgs + t_slice * (double)c;
         if (cost < best * 0.999) { best = cost; sl = c; }
     }
-    if (const char* e = getenv("ZSV_WGRAD_TRING_SLICES")) sl = atol(e) > 0 ? atol(e) : 1;
+    if (const char* e = ZSV_KNOB(WGRAD_TRING_SLICES)) sl = atol(e) > 0 ? atol(e) : 1;
     // the slices take whole (clip, segment) jobs, job j to slice j % slices (see the kernel): no slice without a job
     const long jobs = (long)d->N * (d->Hi * d->Wi / 16);
     if (sl > jobs) sl = jobs;
@@ -556,13 +557,6 @@ static int wgrad_twino_launch(const WgradTringParams& p, int slices, hipStream_t
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_twino_kernel<TM, PRE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    if (const char* e = getenv("ZSV_WGRAD_LDS_PAD")) {          // occupancy experiment: a bigger allocation = one workgroup per CU
-        const int bytes = LDS_BYTES + atoi(e);
-        if (hipFuncSetAttribute((const void*)conv_wgrad_twino_kernel<TM, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
-        hipLaunchKernelGGL((conv_wgrad_twino_kernel<TM, PRE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), bytes, stream, p, x,
-                           dy, out);
-        return launch_status();
-    }
     hipLaunchKernelGGL((conv_wgrad_twino_kernel<TM, PRE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, out);
     return launch_status();

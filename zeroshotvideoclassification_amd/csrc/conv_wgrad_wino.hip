@@ -31,6 +31,7 @@
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -315,7 +316,7 @@ static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
         const double cost = t_mfma * (double)(rounds * resident) / (double)wgs + t_slice * (double)c;
         if (cost < best * 0.999) { best = cost; sl = c; }
     }
-    if (const char* e = getenv("ZSV_WGRAD_WINO_SLICES")) sl = atol(e);
+    if (const char* e = ZSV_KNOB(WGRAD_WINO_SLICES)) sl = atol(e);
     if (sl < 1) sl = 1;
     if (sl > chunks) sl = chunks;
     pl.chunks_per_slice = (int)((chunks + sl - 1) / sl);
@@ -324,7 +325,7 @@ static WgradWinoPlan wgrad_wino_plan(const zsv_conv_desc* d) {
 }
 
 bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* dy) {
-    if (getenv("ZSV_NO_WINO") || getenv("ZSV_NO_WGRAD_WINO")) return false;
+    if (ZSV_KNOB(NO_WINO) || ZSV_KNOB(NO_WGRAD_WINO)) return false;
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
         d->pH != 1 || d->pW != 1)
         return false;
@@ -354,13 +355,6 @@ static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t s
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, TN, EDGE>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    if (const char* e = getenv("ZSV_WGRAD_LDS_PAD")) {          // occupancy experiment: a bigger allocation = one workgroup per CU
-        const int bytes = LDS_BYTES + atoi(e);
-        if (hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<TM, TN, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
-        hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, TN, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), bytes, stream, p, x,
-                           dy, vm, out);
-        return launch_status();
-    }
     hipLaunchKernelGGL((conv_wgrad_wino_kernel<TM, TN, EDGE>), dim3((unsigned)(p.tiles_mn * slices)), dim3(256), LDS_BYTES, stream, p, x,
                        dy, vm, out);
     return launch_status();

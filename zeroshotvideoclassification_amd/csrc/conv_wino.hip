@@ -27,6 +27,7 @@
 #include "conv_params.h"
 #include "zsv_common.h"
 #include "zsv_hip.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -1069,10 +1070,10 @@ static int wino_ksplit(const zsv_conv_desc* d, int M) {
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     const int bm = 16 * wino_tm(M), C = M == d->Cout ? d->Cin : d->Cout;
     const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256), nchunks = (long)((C + 15) / 16) * 3 * d->kT;
-    const char* e = getenv("ZSV_WINO_MIN_TILES");
+    const char* e = ZSV_KNOB(WINO_MIN_TILES);
     const long min_tiles = e ? atol(e) : 512;
     if (tiles >= min_tiles) return 1;
-    if (getenv("ZSV_WINO_NO_SPLITK")) return 0;
+    if (ZSV_KNOB(WINO_NO_SPLITK)) return 0;
     for (long ks = 2; ks <= 4; ++ks)
         if (tiles * ks >= min_tiles && nchunks / ks >= 12) return (int)ks;
     return 0;
@@ -1088,22 +1089,22 @@ static int winot_segs(const zsv_conv_desc* d) {
     return (d->Hi * d->Wi + PW - 1) / PW;
 }
 static bool winot_geometry(const zsv_conv_desc* d, int M) {
-    if (getenv("ZSV_NO_WINO") || getenv("ZSV_NO_WINOT") || !winot_shape(d)) return false;
+    if (ZSV_KNOB(NO_WINO) || ZSV_KNOB(NO_WINOT) || !winot_shape(d)) return false;
     if ((d->Ti != 4 && d->Ti != 8 && d->Ti != 16) || (d->Hi * d->Wi) % 4 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     if ((long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
     const int bm = 16 * wino_tm(M);
     const long tiles = (long)((M + bm - 1) / bm) * d->N * winot_segs(d);
     const long hw = (long)d->Hi * d->Wi, covered = (long)winot_segs(d) * (256 / d->Ti);
-    const char* e1 = getenv("ZSV_WINOT_MIN_TILES");
-    const char* e2 = getenv("ZSV_WINOT_MAX_WASTE");
+    const char* e1 = ZSV_KNOB(WINOT_MIN_TILES);
+    const char* e2 = ZSV_KNOB(WINOT_MAX_WASTE);
     const long min_tiles = e1 ? atol(e1) : 256, max_waste = e2 ? atol(e2) : 35;      // (layer3's 14x14 maps: 196 of 256 positions, 352 tiles: still +15 %)
     return tiles >= min_tiles && covered * 100 <= hw * (100 + max_waste);     // few empty positions in the last segment
 }
 
 static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if (winot_geometry(d, M)) return true;
-    if (getenv("ZSV_NO_WINO")) return false;
+    if (ZSV_KNOB(NO_WINO)) return false;
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
         d->pH != 1 || d->pW != 1)
         return false;
@@ -1118,14 +1119,14 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
 
 // dgrad / forward of a 1x3x3 or 3x3x3 stride-1 "same" convolution with enough voxel tiles to fill the chip
 bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cin); }
-bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
+bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && ZSV_KNOB(NO_WINO_FWD) == nullptr; }
 int wino_fwd_stat_tiles(const zsv_conv_desc* d) {
     if (winot_geometry(d, d->Cout)) return d->N * winot_segs(d);
     return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256);
 }
 
 // W % 4 == 0: the F(4,3) kernel (6 Winograd points), else F(2,3) (4 points)
-static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_F43") == nullptr; }
+static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_F43) == nullptr; }
 static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
     const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
     if (winot_shape(d)) return wino_align((size_t)nblk * 6 * 16 * Mp * sizeof(float));            // (no row taps; 6 points: the F(4,3) form, the F(2,3) form uses 4)
@@ -1161,12 +1162,6 @@ static int wino4_launch(const WinoParams& p, const float* up, const float* in, f
     static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
-    if (const char* e = getenv("ZSV_WINO_LDS_PAD")) {        // occupancy experiment: a bigger allocation = one workgroup per CU
-        const int bytes = LDS_BYTES + atoi(e);
-        if (hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ZSV_E_LAUNCH;
-        hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), bytes, stream, p, up, in, out);
-        return launch_status();
-    }
     hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
@@ -1214,7 +1209,7 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
     p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
     float* up = (float*)workspace;
-    const bool f43 = getenv("ZSV_WINOT_NO_F43") == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
+    const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
     const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
@@ -1265,7 +1260,7 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C,
                        p.nblk, p.R, sm, sc, flip, total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    const bool x4 = d->Wi % 4 == 0 && getenv("ZSV_WINO_NO_X4") == nullptr;
+    const bool x4 = d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_X4) == nullptr;
     int st;
     if (f43) {
         if (tm == 3) st = (p.nblk * p.R == 12 && ks == 1) ? wino4_launch<3, 12>(p, up, in, out, stream) : wino4_launch<3, 0>(p, up, in, out, stream);
@@ -1291,7 +1286,7 @@ int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const fl
                     workspace_bytes, stream);
 }
 
-bool wino_fwd_pre_capable(const zsv_conv_desc* d) { return winot_geometry(d, d->Cout) && getenv("ZSV_NO_WINO_FWD") == nullptr; }
+bool wino_fwd_pre_capable(const zsv_conv_desc* d) { return winot_geometry(d, d->Cout) && ZSV_KNOB(NO_WINO_FWD) == nullptr; }
 
 // the temporal forward with the BatchNorm + ReLU in front of it applied on the fly (conv_winot_kernel PRE)
 int wino_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int pre_pitch, const float* w, float* stat_sum,

@@ -206,11 +206,10 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // gradient both want a pass over dy): g = y > 0 ? dy : 0 written, sum(g) per (channel, slice) in double
 __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                             float* __restrict__ gout, int N, int C, int S, int slices,
-                                                            double* __restrict__ part) {
+                                                            int vec, double* __restrict__ part) {
     __shared__ double red[4];
     const int c = blockIdx.x, sl = blockIdx.y;
     const int total = N * S;
-    const bool vec = (S & 3) == 0;
     int len = (total + slices - 1) / slices;
     if (vec) len = (len + 3) & ~3;
     const int b = min(total, sl * len), e = min(total, b + len);
@@ -380,7 +379,10 @@ extern "C" int zsv_relu_bwd_bias(const float* dy, const float* y, float* g, int3
     if (workspace_bytes < zsv_channel_sum_workspace_bytes(N, C, S)) return ZSV_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int slices = cs_slices(N, C, S);
-    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(C, slices), dim3(256), 0, stream, dy, y, g, N, C, S, slices, (double*)workspace);
+    // float4 path: whole 16-byte pieces per (n, c) row AND 16-byte aligned bases (a contiguous view of a larger buffer may
+    // start at an odd offset)
+    const int vec = (S % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(g)) ? 1 : 0;
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(C, slices), dim3(256), 0, stream, dy, y, g, N, C, S, slices, vec, (double*)workspace);
     int st = launch_status();
     if (st) return st;
     hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)workspace, C, slices, db);

@@ -68,6 +68,11 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 # the calling stream wait for the side stream, so `.grad` is safe to read right after `loss.backward()`.
 _WGRAD_SIDE = {}
 _WGRAD_JOIN_QUEUED = {}
+_WGRAD_SEEN = {}          # device index -> (graph task id, ids of the parameters that already produced a dw in that pass)
+# Two private autograd entry points make the end-of-pass join possible; without them (another torch version) every wgrad
+# launch is followed by an immediate wait on the calling stream -- correct, merely without the overlap.
+_current_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_queue_engine_callback = getattr(getattr(torch.autograd.Variable, "_execution_engine", None), "queue_callback", None)
 
 
 def wgrad_side_stream(device):
@@ -88,10 +93,39 @@ def join_wgrad_streams(stream=None):
             (stream or torch.cuda.current_stream()).wait_stream(st)
 
 
+def _dw_read_early(param, device) -> bool:
+    """Will something read (or add to) this weight gradient on the BACKWARD stream before the pass ends?
+    * the parameter already holds a ``.grad`` (``zero_grad(set_to_none=False)``, gradient accumulation): autograd adds dw to
+      it in place as soon as the backward function returns;
+    * the weight is not a leaf: its gradient keeps flowing through the graph;
+    * tensor hooks (``weight.register_hook``) run on dw right away;
+    * the SAME weight produced a dw earlier in this pass (a module applied twice before backward, siamese / multi-clip
+      forwards, tied weights): autograd's input buffer sums the two on the backward stream when the second one arrives --
+      the first may still be in flight on the side stream."""
+    if param is None:
+        return False
+    if not param.is_leaf or getattr(param, "_backward_hooks", None):
+        return True
+    if param.grad is not None:
+        return True
+    if _current_graph_task_id is None:
+        return True                                    # cannot tell passes apart: be safe
+    key = torch.device(device).index
+    task = _current_graph_task_id()
+    seen = _WGRAD_SEEN.get(key)
+    if seen is None or seen[0] != task or task == -1:
+        seen = _WGRAD_SEEN[key] = (task, set())
+    pid = id(param)
+    if pid in seen[1]:
+        return True
+    seen[1].add(pid)
+    return False
+
+
 def _on_wgrad_stream(launch, inputs, param=None):
     """Run ``launch(stream_handle) -> dw`` on the weight-gradient side stream (or the current stream when it is disabled).
-    ``param``: the parameter the gradient belongs to -- when it already holds a ``.grad`` (``zero_grad(set_to_none=False)``,
-    gradient accumulation) autograd adds ``dw`` to it in place on the backward stream right away, so that stream must wait."""
+    ``param``: the parameter the gradient belongs to; when its dw is consumed on the backward stream before the pass ends
+    (``_dw_read_early``) that stream waits for the side stream right here."""
     dev = inputs[-1].device
     side = wgrad_side_stream(dev)
     if side is None:
@@ -105,24 +139,29 @@ def _on_wgrad_stream(launch, inputs, param=None):
     for t in inputs:
         t.record_stream(side)                          # the side stream reads memory the backward stream owns
     dw.record_stream(main)                             # ... and the optimizer reads dw on the backward stream
-    if param is not None and getattr(param, "grad", None) is not None:
-        main.wait_stream(side)                         # accumulated in place by autograd as soon as this function returns
-    _queue_wgrad_join(dev)
+    if _dw_read_early(param, dev) or not _queue_wgrad_join(dev):
+        main.wait_stream(side)
     return dw
 
 
-def _queue_wgrad_join(device):
+def _queue_wgrad_join(device) -> bool:
     """Once per backward pass (autograd graph task) and device: a callback that runs when the pass ends and makes the
     stream the pass was launched on wait for the weight-gradient stream.  Keyed by the graph task id, so a pass that died
-    with an exception cannot leave a stale "already queued" mark behind."""
+    with an exception cannot leave a stale "already queued" mark behind.  False: this torch has no such hook (the caller
+    joins at once instead)."""
+    if _current_graph_task_id is None or _queue_engine_callback is None:
+        return False
     key = torch.device(device).index
-    task = torch._C._current_graph_task_id()
-    if _WGRAD_JOIN_QUEUED.get(key) == task and task != -1:
-        return
+    task = _current_graph_task_id()
+    if task == -1:                                     # not inside an engine-driven pass (a Function.backward called by hand)
+        return False
+    if _WGRAD_JOIN_QUEUED.get(key) == task:
+        return True
     _WGRAD_JOIN_QUEUED[key] = task
     main = torch.cuda.current_stream(device)
     side = _WGRAD_SIDE[key]
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+    _queue_engine_callback(lambda: main.wait_stream(side))
+    return True
 
 
 class KernelTimer:

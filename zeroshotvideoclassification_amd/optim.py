@@ -84,6 +84,31 @@ class LossScaler:
     def get_scale(self) -> float:
         return self.state()["scale"]
 
+    def state_dict(self) -> dict:
+        """``GradScaler.state_dict()`` keys (``scale``, ``growth_factor``, ``backoff_factor``, ``growth_interval``,
+        ``_growth_tracker``) plus ``steps_done`` -- the count of optimizer steps actually taken, which the Adam bias
+        correction reads on the device.  One host sync."""
+        st = self.state()
+        return {"scale": st["scale"], "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": st["growth_tracker"], "steps_done": st["steps_done"]}
+
+    def load_state_dict(self, state: dict) -> None:
+        """Resume: uploads the 4-word device state.  A ``torch.amp.GradScaler`` state dict is accepted too (no
+        ``steps_done``: the count is then taken from the optimizer when it adopts this scaler)."""
+        self.growth_factor = float(state.get("growth_factor", self.growth_factor))
+        self.backoff_factor = float(state.get("backoff_factor", self.backoff_factor))
+        self.growth_interval = int(state.get("growth_interval", self.growth_interval))
+        host = torch.zeros(4, dtype=torch.int32)
+        host.view(torch.float32)[0] = float(state["scale"])
+        host[1] = int(state.get("_growth_tracker", 0))
+        host[3] = int(state.get("steps_done", 0))
+        self._state.copy_(host)
+
+    def _seed_steps_done(self, steps: int) -> None:
+        host = self._state.cpu()
+        host[3] = int(steps)
+        self._state.copy_(host)
+
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_buckets=None):
@@ -95,6 +120,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.grad_buckets = grad_buckets                  # ddp.GradientSync (or None)
         self._static = None                               # (layout_version, table, count, chunks, [(p, grad ptr)], flats)
         self._host_steps = 0                              # steps taken without a scaler
+        self._resumed = False                             # state came from load_state_dict (a scaler may then join late)
         self._scaler: Optional[LossScaler] = None
 
     # -- descriptor tables ------------------------------------------------------------------------
@@ -203,24 +229,36 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         if scaler is not None and self._scaler is None:
             if self._host_steps:
-                raise RuntimeError("FusedAdam: a LossScaler must drive the optimizer from its first step "
-                                   "(the count of steps taken lives in the scaler's device state)")
+                if not self._resumed:
+                    raise RuntimeError("FusedAdam: a LossScaler must drive the optimizer from its first step "
+                                       "(the count of steps taken lives in the scaler's device state)")
+                # resumed from a checkpoint (load_state_dict): the scaler takes over the loaded step count unless its own
+                # loaded state already carries one
+                if scaler.state()["steps_done"] == 0:
+                    scaler._seed_steps_done(self._host_steps)
+                elif scaler.state()["steps_done"] != self._host_steps:
+                    raise RuntimeError("FusedAdam: the loaded optimizer and scaler states disagree on the steps taken")
             self._scaler = scaler
         if self._scaler is not None and scaler is not self._scaler:
             raise RuntimeError("FusedAdam: this optimizer is driven by a LossScaler; step through scaler.step(optimizer)")
         lib = _lib.load()
         launched = False
+        work = []
         for group in self.param_groups:
             built = self._static_table(group) or self._dynamic_table(group)
-            if built is None:
-                continue
-            table, count, chunks, keep = built
-            dev = table.device
-            lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
-            with torch.cuda.device(dev):
-                if scaler is not None:
+            if built is not None:
+                work.append((group, built))
+        if scaler is not None:
+            # GradScaler.step checks EVERY gradient before the optimizer touches anything: an inf in the last group must
+            # skip the first group's update too
+            for _, (table, count, chunks, _keep) in work:
+                with torch.cuda.device(table.device):
                     _lib.check(lib.zsv_grad_check_multi(table.data_ptr(), count, chunks, scaler.state_ptr, _stream()),
                                "zsv_grad_check_multi")
+        for group, (table, count, chunks, keep) in work:
+            lr, (b1, b2), eps = float(group["lr"]), group["betas"], float(group["eps"])
+            with torch.cuda.device(table.device):
+                if scaler is not None:
                     _lib.check(lib.zsv_adam_multi_scaled(table.data_ptr(), count, chunks, lr, float(b1), float(b2), eps,
                                                          scaler.state_ptr, _stream()), "zsv_adam_multi_scaled")
                 else:
@@ -230,6 +268,7 @@ class FusedAdam(torch.optim.Optimizer):
             table.record_stream(torch.cuda.current_stream())
             del keep
             launched = True
+        del work
         if launched:
             if scaler is None:
                 self._host_steps += 1
@@ -246,6 +285,8 @@ class FusedAdam(torch.optim.Optimizer):
         if steps and min(steps) != max(steps):
             raise RuntimeError("FusedAdam: the loaded per-parameter step counts differ")
         self._host_steps = steps[0] if steps else 0
+        self._resumed = True
+        self._scaler = None
         for st in self.state.values():
             if "step" in st:
                 st["step"] = st["step"].detach().to("cpu", torch.float32)

@@ -70,7 +70,8 @@ class ClipTransform:
         for (i, j, _f) in params:
             if not (0 <= i <= hres - self.crop_size and 0 <= j <= wres - self.crop_size):
                 raise RuntimeError("crop window outside the resized frame")
-        ptab = torch.tensor(params, dtype=torch.int32).to(frames_u8.device)
+        # pinned + non_blocking: a pageable upload would drain the stream every call (the host could no longer run ahead)
+        ptab = torch.tensor(params, dtype=torch.int32).pin_memory().to(frames_u8.device, non_blocking=True)
         out = torch.empty((n, 3, t, self.crop_size, self.crop_size), dtype=torch.float32, device=frames_u8.device)
         with torch.cuda.device(frames_u8.device):
             _lib.check(_lib.load().zsv_clip_transform(frames_u8.data_ptr(), n, t, h, w, hres, wres, float(inv_scale),

@@ -25,7 +25,7 @@ from ctypes import c_void_p
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 _PREFIX = "module."       # nn.DataParallel's prefix in saved checkpoints (main.py:116,126,363)
@@ -71,6 +71,7 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criteri
     y = embed(model, x)
     loss = criterion(y, z)
     (scaler.scale(loss) if scaler is not None else loss).backward()
+    ops.join_wgrad_streams()          # (the autograd end-of-pass callback has done this already; a no-op wait then)
     if grad_sync is not None:
         grad_sync.finish_step()
     if scaler is not None:
@@ -150,7 +151,8 @@ def _gather_rows(t: torch.Tensor, group) -> torch.Tensor:
 @torch.no_grad()
 def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], class_embed: torch.Tensor,
              device: Optional[torch.device] = None, splits: int = 10, dtype: Optional[torch.dtype] = None,
-             group=None, sharded: Optional[bool] = None) -> dict:
+             group=None, sharded: Optional[bool] = None, local_batches: bool = False,
+             sync_state: bool = True) -> dict:
     """main.py:224-313 for one test set.  ``batches`` yields ``(X, labels, Z, ...)``; samples with
     label -1 (failed loads, auxiliary_dataset.py:502-505) are dropped like main.py:246-248.
     ``dtype=torch.bfloat16`` runs the forward on the bf16 engine (``inference.Bf16Engine``, the
@@ -159,15 +161,26 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
 
     With ``torch.distributed`` initialised (one process per GPU; ``sharded`` defaults to that) every rank
     iterates the SAME ``batches`` and runs the forward for every ``world``-th one (batch ``i`` belongs to
-    rank ``i % world``); the ``(pred, true, label)`` rows are all-gathered over ``group`` (RCCL) and every
-    rank computes the same accuracies.  The reference evaluates under one-process ``nn.DataParallel``
-    (main.py:126,250), which scatters each batch instead: same samples, same result."""
+    rank ``i % world``); with ``local_batches=True`` the iterable is this rank's OWN shard (a per-rank loader:
+    nothing is skipped, no rank decodes another rank's clips).  The ``(pred, true, label)`` rows are
+    all-gathered over ``group`` (RCCL) and every rank computes the same accuracies.  The reference evaluates
+    under one-process ``nn.DataParallel`` (main.py:126,250), which scatters each batch and runs every replica
+    with DEVICE 0's parameters and BatchNorm running statistics.  Data-parallel training keeps those statistics
+    per replica (``ddp.GradientSync``), so before a sharded evaluation every rank takes rank 0's parameters and
+    buffers (``sync_state``; one broadcast per tensor): all samples are scored by ONE model -- the one rank 0
+    would checkpoint (main.py:361-365).  ``sync_state=False`` skips the broadcast when the caller knows the
+    replicas are identical (e.g. right after ``load_weights`` on every rank)."""
     import torch.distributed as dist
     if sharded is None:
         sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if sharded else (0, 1)
     was_training = model.training
     model.eval()
+    if sharded and sync_state:
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+        _lib.note_raw_write()                              # `.data` writes: cached folded-BatchNorm engines must rebuild
     device = device or next(model.parameters()).device
     forward = model
     if dtype in (torch.bfloat16, torch.float32):
@@ -177,7 +190,7 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
         raise RuntimeError(f"evaluate: dtype {dtype} is not supported (fp32 or bf16)")
     preds, trues, labels = [], [], []
     for index, batch in enumerate(batches):
-        if index % world != rank:
+        if not local_batches and index % world != rank:
             continue
         x, l, z = batch[0], batch[1], batch[2]
         keep = l != -1
