@@ -222,6 +222,39 @@ def run_transforms():
     return out
 
 
+# multi-frame clips (the single-frame fixtures above cannot see a frame-index error): one validation and one training case
+TRANSFORM_T4 = [("val", 120, 160, 4), ("train", 200, 130, 4)]
+
+
+def run_transforms_t4():
+    """The same two chains of the reference on 4-frame clips (``tests/golden/transforms_t4.npz``)."""
+    import random
+    from zeroshotvideoclassification_amd import preprocess
+    RT = import_reference_transforms()
+    out = {"cases": np.array([f"{kind}_{h}x{w}x{t}" for kind, h, w, t in TRANSFORM_T4])}
+    for k, (kind, h, w, t) in enumerate(TRANSFORM_T4):
+        clip = transform_input(h, w, t)
+        hres, wres, _ = preprocess.resized_hw(h, w, 128)
+        if kind == "val":
+            got = RT.get_transform(True)(clip)
+            ci, cj = TO.center_crop_params(hres, wres, 112, 112)
+            assert torch.equal(got, TO.clip_transform(clip, ci, cj, False)), "restatement differs (validation chain, T=4)"
+            params = [0, ci, cj, 0]
+        else:
+            seed = 200 + k
+            random.seed(seed)
+            got = RT.get_transform(False)(clip)
+            random.seed(seed)
+            (i, j, f), = preprocess.ClipTransform(False).draw_params(1, hres, wres)
+            assert torch.equal(got, TO.clip_transform(clip, i, j, bool(f))), "restatement / draw order differs (training chain, T=4)"
+            params = [seed, i, j, f]
+        assert tuple(got.shape) == (3, t, 112, 112)
+        assert not torch.equal(got[:, 0], got[:, 1])                      # frames differ: an index mix-up would show
+        out[f"{kind}_{h}x{w}x{t}"] = got.numpy()
+        out[f"{kind}_params_{h}x{w}x{t}"] = np.array(params)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # evaluate() / compute_accuracy() (SURVEY a15): the reference's own functions on synthetic embeddings
 EVAL_SETS = [dict(name="ucf101", classes=101, n=1500), dict(name="hmdb51", classes=51, n=900),
@@ -332,12 +365,34 @@ def run_surface_extras():
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# config E at batch size > 1: 32-frame eval embeddings of the reference for FOUR clips (the per-case fixture holds one)
+def run_t32_batch():
+    """``emb_eval_t32_f32``: R(2+1)D-18 ``Model`` in eval mode (jittered BatchNorm statistics) on 4 clips of 32 frames at
+    112x112, from the imported reference; the bf16 engine and the folded fp32 engine are checked against it."""
+    ref_network, _ = import_reference()
+    opt = R.make_opt("r2plus1d_18")
+    ref = ref_network.get_network(opt)
+    mine = R.oracle_network(opt)
+    weights = S.keyed_state_dict(ref.state_dict(), seed=0, bn_jitter=True)
+    ref.load_state_dict(weights)
+    mine.load_state_dict(weights)
+    ref.eval(); mine.eval()
+    x = S.synthetic_clips(4, 32, 112, seed=199)
+    with torch.no_grad():
+        y = R.embed(ref, x)
+        assert torch.equal(y, R.embed(mine, x)), "restatement differs from the reference (T=32 eval, N=4)"
+    return {"emb_eval_t32_f32": y.numpy(), "meta_n": np.array(4), "meta_frames": np.array(32), "meta_size": np.array(112),
+            "meta_seed": np.array(199), "meta_bn_jitter": np.array(True), "meta_network": np.array("r2plus1d_18")}
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     ref_network, _ = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
-    for name, fn in (("transforms", run_transforms), ("accuracy", run_accuracy), ("surface_extras", run_surface_extras)):
+    for name, fn in (("transforms", run_transforms), ("transforms_t4", run_transforms_t4), ("accuracy", run_accuracy),
+                     ("surface_extras", run_surface_extras), ("r2plus1d_t32_batch", run_t32_batch)):
         if only and name not in only:
             continue
         t0 = time.time()

@@ -41,18 +41,43 @@ def _no_download(*_a, **_k):
     raise RuntimeError("offline: pretrained weights are never loaded (SURVEY F3)")
 
 
+class _Compose:                                           # torchvision.transforms.Compose: apply in order
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def _ensure_torchvision():
+    """The real ``torchvision`` when it imports; otherwise ONE stub package carrying every arithmetic-free symbol either
+    importer needs (``resnet.py:6-7``: ``_internally_replaced_utils.load_state_dict_from_url``, ``utils._log_api_usage_once``;
+    ``auxiliary/transforms.py:56``: ``transforms.Compose``).  Both importers call this, so their order does not matter (a
+    stub left by the first call used to satisfy the second call's ``import torchvision`` while lacking its sub-modules)."""
+    existing = sys.modules.get("torchvision")
+    if existing is None or not getattr(existing, "__zsv_stub__", False):
+        try:
+            importlib.import_module("torchvision")
+            importlib.import_module("torchvision.transforms")
+            return
+        except Exception:
+            for name in [n for n in sys.modules if n == "torchvision" or n.startswith("torchvision.")]:
+                del sys.modules[name]                    # a half-imported package must not shadow the stub
+    tv = _stub("torchvision")
+    tv.__dict__.setdefault("__path__", [])               # a package: `from torchvision.x import y` resolves through sys.modules
+    tv._internally_replaced_utils = _stub("torchvision._internally_replaced_utils", load_state_dict_from_url=_no_download)
+    tv.utils = _stub("torchvision.utils", _log_api_usage_once=lambda *_a, **_k: None)
+    tv.transforms = _stub("torchvision.transforms", Compose=_Compose)
+
+
 def import_reference():
     """Returns the reference's ``(network, resnet)`` modules."""
     if not reference_available():
         raise FileNotFoundError(REFERENCE_ROOT)
     sys.dont_write_bytecode = True
-    try:
-        importlib.import_module("torchvision")
-    except Exception:
-        tv = _stub("torchvision")
-        tv._internally_replaced_utils = _stub(
-            "torchvision._internally_replaced_utils", load_state_dict_from_url=_no_download)
-        tv.utils = _stub("torchvision.utils", _log_api_usage_once=lambda *_a, **_k: None)
+    _ensure_torchvision()
     try:
         importlib.import_module("gensim.models")
     except Exception:
@@ -91,20 +116,7 @@ def import_reference_transforms():
     except Exception:
         _stub("imageio")
 
-    class Compose:                                        # torchvision.transforms.Compose: apply in order
-        def __init__(self, transforms):
-            self.transforms = transforms
-
-        def __call__(self, x):
-            for t in self.transforms:
-                x = t(x)
-            return x
-
-    try:
-        importlib.import_module("torchvision.transforms")
-    except Exception:
-        tv = _stub("torchvision")
-        tv.transforms = _stub("torchvision.transforms", Compose=Compose)
+    _ensure_torchvision()
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     mod = sys.modules.get("auxiliary.transforms")

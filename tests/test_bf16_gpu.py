@@ -172,6 +172,31 @@ def test_engine_matches_oracle_fixture_t32():
     assert (emb - ref).abs().max().item() <= 2e-2
 
 
+def test_engines_match_the_reference_fixture_t32_batch_of_4():
+    """Config E at a batch size > 1: the reference's own eval-mode embeddings of FOUR 32-frame clips
+    (tests/golden/r2plus1d_t32_batch.npz, written by oracle/make_golden.py::run_t32_batch from the imported network.py).
+    bf16 engine: 2e-2 absolute / cosine >= 0.999 per clip; folded fp32 engine and the module forward: 1e-4 relative."""
+    from helpers import load_golden, make_opt
+    from zeroshotvideoclassification_amd import network
+    g = load_golden("r2plus1d_t32_batch")
+    model = network.get_network(make_opt(str(g["meta_network"])))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=bool(g["meta_bn_jitter"])))
+    model.to(DEV).eval()
+    x = synthetic.synthetic_clips(int(g["meta_n"]), int(g["meta_frames"]), int(g["meta_size"]), seed=int(g["meta_seed"])).to(DEV)
+    ref = torch.from_numpy(g["emb_eval_t32_f32"]).to(DEV)
+    assert ref.shape == (4, 300)
+    emb, _ = inference.Bf16Engine(model)(x)
+    cos = (emb * ref).sum(dim=1)
+    assert cos.min().item() >= 0.999, cos
+    assert (emb - ref).abs().max().item() <= 2e-2
+    with torch.no_grad():
+        plain, _ = model(x)
+    folded, _ = inference.Fp32Engine(model)(x)
+    scale = ref.abs().max().item()
+    assert (plain - ref).abs().max().item() <= 1e-4 * scale
+    assert (folded - ref).abs().max().item() <= 1e-4 * scale
+
+
 def test_engine_ranking_agrees_with_fp32():
     """Nearest-class ranking (main.py:316-325) from bf16 embeddings vs fp32 embeddings."""
     model = _model("r2plus1d_18", seed=3)

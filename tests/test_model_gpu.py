@@ -308,6 +308,37 @@ def test_full_size_gradients_match_the_oracle_per_parameter(net, n, train_mode):
     assert len(got) == (115 if net == "r2plus1d_18" else 20)          # 115 of 193 (R(2+1)D-18 + head), 20 of 24 (fc7 / fc8 unused)
 
 
+def test_c3d_at_the_benchmark_batch_matches_the_oracle_forward():
+    """BASELINE configs[3] at the batch the bench runs (22 clips; the per-parameter gradient check above stays at 4): conv1's
+    1.13 GB output, the tile / slice choices of every layer at N = 22.  Embeddings and loss against the CPU oracle on the same
+    weights and clips (eval mode: dropout off), and the backward at that size must produce finite gradients for exactly the live set."""
+    opt = make_opt("c3d")
+    model = network.get_network(opt)
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(weights)
+    n = 22
+    x = synthetic.synthetic_clips(n, 16, 112)
+    _, z = synthetic.synthetic_targets(n)
+    from oracle import restatement as R
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    oracle = R.oracle_network(opt)
+    oracle.load_state_dict(weights)
+    oracle.eval()
+    with torch.no_grad():
+        y_ref = R.embed(oracle, x)
+        loss_ref = F.mse_loss(y_ref, z)
+    model.to(DEV).eval()
+    y = train.embed(model, x.to(DEV))
+    loss = F.mse_loss(y, z.to(DEV))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert y.shape == (n, 300)
+    assert rel_err(y.detach().cpu().numpy(), y_ref.numpy()) < TIGHT
+    assert abs(loss.item() / loss_ref.item() - 1) < TIGHT
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert len(grads) == 20 and all(torch.isfinite(g).all().item() for g in grads.values())
+
+
 def test_mc3_18_trunk_matches_oracle_trunk():
     """resnet.mc3_18 (resnet.py:318-338) is not reachable through get_network but is part of the
     module surface: 3x3x3 first stage, 1x3x3 (Conv3DNoTemporal, shortcut stride (1,s,s)) afterwards."""

@@ -77,3 +77,32 @@ def test_restatement_is_pinned_to_the_imported_reference(name):
         assert (p.grad is None) == (q.grad is None), k
         if p.grad is not None:
             assert torch.equal(p.grad, q.grad), k
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference exists only in the build container")
+@pytest.mark.parametrize("order", ["transforms_first", "network_first"])
+def test_reference_importers_work_in_either_order(order):
+    """oracle/reference_import.py: the torchvision stand-in installed by one importer must not break the other (a stub
+    ``torchvision`` without its sub-modules used to satisfy the second importer's ``import torchvision``)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    calls = ["t = RI.import_reference_transforms(); assert t.get_transform(True)", "n, r = RI.import_reference(); assert n.get_network and r.r2plus1d_18"]
+    if order == "network_first":
+        calls.reverse()
+    code = "from oracle import reference_import as RI; " + "; ".join(calls) + "; print('ok')"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-800:]
+
+
+def test_t32_batch_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/r2plus1d_t32_batch.npz (reference output, 4 clips x 32 frames, eval mode) against the restatement."""
+    g = load_golden("r2plus1d_t32_batch")
+    model = R.oracle_network(R.make_opt(str(g["meta_network"])))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=bool(g["meta_bn_jitter"])))
+    model.eval()
+    x = synthetic.synthetic_clips(int(g["meta_n"]), int(g["meta_frames"]), int(g["meta_size"]), seed=int(g["meta_seed"]))
+    with torch.no_grad():
+        y = R.embed(model, x)
+    assert rel_err(y.numpy(), g["emb_eval_t32_f32"]) < 1e-5

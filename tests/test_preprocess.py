@@ -63,6 +63,50 @@ def test_clip_transform_matches_the_reference_fixtures():
         assert (out[0] - trn).abs().max().item() < 2e-6, (h, w)
 
 
+def _golden_t4_cases():
+    """Multi-frame fixtures (tests/golden/transforms_t4.npz): a frame-index error cannot hide in these."""
+    g = load_golden("transforms_t4")
+    for name in (str(c) for c in g["cases"]):
+        kind, dims = name.split("_")
+        h, w, t = (int(v) for v in dims.split("x"))
+        clip = torch.randint(0, 256, (t, h, w, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(h * 1000 + w))
+        seed, i, j, f = (int(v) for v in g[f"{kind}_params_{dims}"])
+        yield kind, h, w, t, clip, torch.from_numpy(g[name]), (seed, i, j, f)
+
+
+def test_restatement_reproduces_the_multi_frame_fixtures():
+    n = 0
+    for kind, h, w, t, clip, want, (seed, i, j, f) in _golden_t4_cases():
+        assert want.shape == (3, t, 112, 112) and t >= 4
+        hres, wres, _ = preprocess.resized_hw(h, w, 128)
+        if kind == "train":
+            random.seed(seed)
+            assert preprocess.ClipTransform(False).draw_params(1, hres, wres) == [(i, j, f)]
+        else:
+            assert (i, j) == TO.center_crop_params(hres, wres, 112, 112)
+        assert torch.equal(TO.clip_transform(clip, i, j, bool(f)), want)
+        n += 1
+    assert n == 2
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference exists only in the build container")
+def test_multi_frame_fixtures_are_outputs_of_the_imported_reference():
+    from oracle.reference_import import import_reference_transforms
+    RT = import_reference_transforms()
+    for kind, h, w, t, clip, want, (seed, i, j, f) in _golden_t4_cases():
+        random.seed(seed)
+        assert torch.equal(RT.get_transform(kind == "val")(clip), want)
+
+
+@pytest.mark.gpu
+def test_clip_transform_matches_the_multi_frame_fixtures():
+    for kind, h, w, t, clip, want, (seed, i, j, f) in _golden_t4_cases():
+        random.seed(seed)
+        out = preprocess.get_transform(kind == "val")(clip.unsqueeze(0).cuda()).cpu()
+        assert out.shape == (1, 3, t, 112, 112)
+        assert (out[0] - want).abs().max().item() < 2e-6, (kind, h, w)
+
+
 def test_resized_geometry_matches_interpolate():
     for (h, w) in [(120, 160), (240, 320), (128, 171), (256, 128), (113, 200)]:
         hres, wres, _ = preprocess.resized_hw(h, w, 128)
