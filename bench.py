@@ -370,7 +370,7 @@ def extra_c3d(dev, steps=5, warmup=2):
     """BASELINE.json configs[3] for the driver's record: C3D training step at 22 clips (network.py:95-180)."""
     from types import SimpleNamespace
     from zeroshotvideoclassification_amd import network, ops, synthetic, train
-    model = network.get_network(SimpleNamespace(network="c3d", fixconvs=False, nopretrained=True))
+    model = network.get_network(SimpleNamespace(network="c3d", fixconvs=False, nopretrained=False))   # (network.py:128-131: True would read ./assets/c3d.pickle)
     model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
     model.to(dev).train()
     criterion = torch.nn.MSELoss().to(dev)

@@ -1097,3 +1097,85 @@ def test_relu_bwd_bias_on_misaligned_views(offset):
     ref = torch.where(y > 0, dy, torch.zeros_like(dy))
     assert torch.equal(gd.cpu(), ref)
     close(db, ref.double().sum(dim=(0, 2)), what="bias gradient")
+
+
+@pytest.mark.parametrize("n,cin,cout,hw", [(5, 921, 512, (7, 7)), (22, 1152, 512, (7, 7)), (2, 45, 70, (5, 6)), (3, 64, 48, (8, 8))],
+                         ids=["T9", "T10_full_batch", "odd_channels", "whole_pieces"])
+def test_two_frame_temporal_conv_in_dense_form(n, cin, cout, hw, monkeypatch):
+    """Conv3d(k=(3,1,1), pad (1,0,0)) on TWO frames (resnet.py:46-52 at layer4) runs as a dense 1x1x1 convolution over
+    (channel, frame) pairs -- 4 instead of 6 products per (co, c, position), csrc/conv_params.h t2_dense_shape.  Forward, input
+    gradient and weight gradient against torch CPU fp64 and against the direct kernels (ZSV_NO_T2_DENSE=1)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, 2, *hw, generator=g)
+    w = torch.randn(cout, cin, 3, 1, 1, generator=g) / np.sqrt(3 * cin)
+    dy = torch.randn(n, cout, 2, *hw, generator=g)
+
+    def run():
+        xd = x.to(DEV).requires_grad_()
+        wd = w.to(DEV).requires_grad_()
+        y = ops.conv3d(xd, wd, None, 1, (1, 0, 0))
+        y.backward(dy.to(DEV))
+        torch.cuda.synchronize()
+        return y.detach(), xd.grad, wd.grad
+
+    dense = run()
+    monkeypatch.setenv("ZSV_NO_T2_DENSE", "1")
+    direct = run()
+    monkeypatch.delenv("ZSV_NO_T2_DENSE")
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = F.conv3d(xr, wr, padding=(1, 0, 0))
+    yr.backward(dy.double())
+    for got, other, ref, what in zip(dense, direct, (yr, xr.grad, wr.grad), ("forward", "dgrad", "wgrad")):
+        close(got, ref, what=f"dense {what}")
+        close(got, other.double(), rtol=1e-5, what=f"dense vs direct {what}")
+    assert not torch.equal(dense[0], direct[0]), "the dense and the direct form should not be the same kernel path"
+
+
+def test_weight_gradient_slab_sum_rows_equals_the_generic_sum(monkeypatch):
+    """conv_wgrad.hip: few slices of a large gradient are added by slab_sum_rows_kernel (coalesced, LDS-transposed) -- same
+    slice order as slab_sum_kernel, so the same bits (ZSV_NO_SLAB_SUM_ROWS=1 selects the generic kernel)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 96, 2, 7, 7, generator=g).to(DEV)
+    dy = torch.randn(6, 200, 2, 7, 7, generator=g).to(DEV)
+    w = torch.randn(200, 96, 1, 3, 3, generator=g).to(DEV)
+
+    def wgrad():
+        xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+        ops.conv3d(xd, wd, None, 1, (0, 1, 1)).backward(dy)
+        torch.cuda.synchronize()
+        return wd.grad
+
+    a = wgrad()
+    monkeypatch.setenv("ZSV_NO_SLAB_SUM_ROWS", "1")
+    b = wgrad()
+    assert torch.equal(a, b)
+    ref = torch.nn.grad.conv3d_weight(x.double().cpu(), w.shape, dy.double().cpu(), padding=(0, 1, 1))
+    close(a, ref, what="wgrad")
+
+
+def test_tiled_weight_pack_equals_the_elementwise_pack(monkeypatch):
+    """conv_tap.hip: pack_weights_tiled_kernel (coalesced reads and writes through an LDS tile) writes exactly the panel of
+    pack_weights_kernel: forward and both gradients of direct-kernel layers are bit-identical with ZSV_NO_PACK_TILED=1."""
+    cases = [((4, 128, 4, 14, 14), (300, 128, 1, 3, 3), (1, 2, 2), (0, 1, 1)),       # strided spatial (forward + class-by-class packs)
+             ((3, 200, 4, 7, 7), (120, 200, 3, 1, 1), (2, 1, 1), (1, 0, 0)),         # strided temporal
+             ((3, 96, 2, 7, 7), (130, 96, 1, 3, 3), 1, (0, 1, 1)),                   # odd width: direct kernel
+             ((2, 40, 3, 6, 6), (50, 40, 3, 3, 3), (2, 2, 2), (1, 1, 1))]            # 27 taps, 8 residue classes
+    for xs, ws, stride, pad in cases:
+        g = torch.Generator().manual_seed(xs[1])
+        x, w = torch.randn(*xs, generator=g).to(DEV), (torch.randn(*ws, generator=g) / 10).to(DEV)
+
+        def run():
+            xd, wd = x.clone().requires_grad_(), w.clone().requires_grad_()
+            y = ops.conv3d(xd, wd, None, stride, pad)
+            y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+            torch.cuda.synchronize()
+            return y.detach(), xd.grad, wd.grad
+
+        a = run()
+        monkeypatch.setenv("ZSV_NO_PACK_TILED", "1")
+        b = run()
+        monkeypatch.delenv("ZSV_NO_PACK_TILED")
+        for u, v in zip(a, b):
+            assert torch.equal(u, v), (xs, ws)
+        ref = F.conv3d(x.double().cpu(), w.double().cpu(), stride=stride, padding=pad)
+        close(a[0], ref, what=f"forward {ws}")

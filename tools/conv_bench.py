@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--shapes", default="S1,T1")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--markers", action="store_true",
+                    help="launch a one-element fill kernel in front of every (shape, kind) group: tools/kernel_breakdown.py splits a "
+                         "rocprofv3 kernel trace of this run at those markers")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda")
@@ -88,6 +91,9 @@ def main():
         }
         for kind in args.kinds.split(","):
             fn = calls[kind]
+            if args.markers:
+                print(f"MARK {name} {kind} {flops:.0f}", flush=True)
+                torch.empty(1, device=dev).fill_(1.0)
             for _ in range(2):
                 assert fn() == 0
             torch.cuda.synchronize()

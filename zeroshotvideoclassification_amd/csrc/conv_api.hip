@@ -85,15 +85,28 @@ const zsv_conv_desc linear_desc(int32_t rows, int32_t in_features, int32_t out_f
 // workspace layout of a tap-kernel call: [packed weights (16-B aligned)] [split-K slabs]
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
-    if (conv_check(d) != ZSV_OK) return 0;
-    if (wino_fwd_applicable(d)) return wino_fwd_workspace_bytes(d);
+// two-frame temporal convolutions in dense 1x1x1 form (conv_params.h: t2_dense_shape)
+static bool t2_dense(const zsv_conv_desc* d) { return t2_dense_shape(d) && !ZSV_KNOB(NO_T2_DENSE); }
+
+static size_t tap_fwd_workspace(const zsv_conv_desc* d) {
     IgemmParams p;
     fwd_params(p, d, 0);
     if (!igemm_tap_applicable(p)) return 0;
     const int ks = igemm_tap_ksplit(p);
     const size_t out_elems = (size_t)d->N * d->Cout * d->To * d->Ho * d->Wo;
     return align256(igemm_tap_workspace_bytes(p)) + (ks > 1 ? (size_t)ks * out_elems * sizeof(float) : 0);
+}
+
+extern "C" size_t zsv_conv3d_fwd_workspace_bytes(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK) return 0;
+    if (wino_fwd_applicable(d)) return wino_fwd_workspace_bytes(d);
+    size_t need = tap_fwd_workspace(d);
+    if (t2_dense(d)) {                   // (calls with a bias / ReLU / residual / statistics take the ordinary path: cover both)
+        const zsv_conv_desc d2 = t2_dense_desc(d);
+        const size_t b = tap_fwd_workspace(&d2);
+        if (b > need) need = b;
+    }
+    return need;
 }
 
 extern "C" int32_t zsv_conv3d_fwd_stat_tiles(const zsv_conv_desc* d, const float* y) {
@@ -143,6 +156,25 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
         return wino_fwd(d, x, w, bias, residual, fuse_relu ? 1 : 0, bn_partials,
                         bn_partials ? bn_partials + (size_t)d->Cout * stat_tiles : nullptr, y, workspace, workspace_bytes,
                         (hipStream_t)stream);
+    }
+    if (t2_dense(d) && !bias && !fuse_relu && !residual && !bn_partials) {
+        const zsv_conv_desc d2 = t2_dense_desc(d);
+        IgemmParams p;
+        fwd_params(p, &d2, 0);
+        p.t2_cin = d->Cin;
+        if (igemm_tap_applicable(p)) {
+            const size_t need = tap_fwd_workspace(&d2);
+            if (workspace_bytes < need || !workspace) return ZSV_E_WORKSPACE;
+            const int ks = igemm_tap_ksplit(p);
+            const size_t wbytes = align256(igemm_tap_workspace_bytes(p));
+            const long out_elems = (long)d->N * d->Cout * d->To * d->Ho * d->Wo;
+            float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
+            p.ksplit = ks;
+            p.slab_elems = (int)out_elems;
+            st = igemm_tap(p, w, 0, 0, x, nullptr, y, workspace, wbytes, slabs, (hipStream_t)stream);
+            if (st || ks <= 1) return st;
+            return splitk_reduce(slabs, ks, out_elems, d2.Cout, p.oS, nullptr, 0, y, (hipStream_t)stream);
+        }
     }
     IgemmParams p;
     fwd_params(p, d, fuse_relu);
@@ -243,6 +275,8 @@ extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
     if (wino_dgrad_applicable(d)) return wino_dgrad_workspace_bytes(d);
     if (dgrad_s2_applicable(d)) return dgrad_s2_workspace_bytes(d);
+    zsv_conv_desc d2;
+    if (t2_dense(d)) { d2 = t2_dense_desc(d); d = &d2; }
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const size_t out_elems = (size_t)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -253,6 +287,7 @@ extern "C" size_t zsv_conv3d_dgrad_workspace_bytes(const zsv_conv_desc* d) {
 extern "C" int32_t zsv_conv3d_dgrad_add_supported(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK || d->sT != 1 || d->sH != 1 || d->sW != 1) return 0;
     if (wino_dgrad_applicable(d)) return wino_dgrad_fusable(d) ? 1 : 0;
+    if (t2_dense(d)) return 0;
     IgemmParams p;
     if (!dgrad_class_params(p, d, 0, 0, 0) || p.K == 0 || !igemm_tap_applicable(p)) return 0;
     size_t wbytes;
@@ -272,6 +307,9 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
     if (add != nullptr && !zsv_conv3d_dgrad_add_supported(d)) return ZSV_E_UNSUPPORTED;
     if (wino_dgrad_applicable(d)) return wino_dgrad(d, dy, w, add, dx, workspace, workspace_bytes, (hipStream_t)stream);
     if (dgrad_s2_applicable(d)) return dgrad_s2(d, dy, w, nullptr, 1, dx, workspace, workspace_bytes, (hipStream_t)stream);     // (stride 2: no `add`)
+    zsv_conv_desc d2;
+    int t2_cin = 0;
+    if (t2_dense(d)) { t2_cin = d->Cin; d2 = t2_dense_desc(d); d = &d2; }
     size_t wbytes;
     const int ks = dgrad_plan(d, wbytes);
     const long out_elems = (long)d->N * d->Cin * d->Ti * d->Hi * d->Wi;
@@ -298,6 +336,7 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
                     p.ksplit = ks;
                     p.slab_elems = (int)out_elems;
                     p.acc_src = add;
+                    p.t2_cin = t2_cin;
                     st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, wbytes, slabs,
                                    (hipStream_t)stream);
                 } else {

@@ -36,10 +36,35 @@ struct IgemmParams {
     int tiles_n;
     const float* pre_coef;  // != nullptr: the gathered tensor is read as relu(g * scale[c] + shift[c]) -- a BatchNorm + ReLU that
     int pre_pitch;          //   was never materialised; [2][pre_pitch] floats (scale row, shift row), zero beyond gC (conv_tap.hip PRE)
+    int t2_cin;             // != 0: the two-frame temporal convolution in dense form (t2_dense below): M, gC are the DOUBLED channel
+                            //   counts, the weight element of (row m, reduction channel c) is read from the ORIGINAL tensor
+                            //   W[Cout][t2_cin][3]; the pack kernels ignore a_m_stride / a_c_stride then
     const float* acc_src;   // != nullptr (no split-K): C = act(result + acc_src + bias), acc_src laid out like C -- the
                             //   gradient of an identity shortcut in a dgrad, or `out += residual` of an inference forward
                             //   (resnet.py:110), added in the epilogue
 };
+
+// ---- a 3x1x1 stride-1 pad-1 convolution over TWO frames is a dense 1x1x1 convolution --------------------------------
+// (resnet.py:46-52 at layer4: T9 / T10, 921 -> 512 and 1152 -> 512 channels on 2x7x7 maps.)  out[co][to] = sum_{c,kt}
+// W[co][c][kt] * x[c][to + kt - 1]: with T = 2 every (to, ti) pair has exactly one tap kt = ti - to + 1 in range, so with
+// channel indices c' = 2c + ti and co' = 2co + to -- which is how (c, t) pairs already lie in an NCDHW tensor with two frames:
+// x[n][c][t][hw] = x'[n][2c + t][hw] -- the layer is y' = W' x' with a dense W'[2 Cout][2 Cin], W'[co'][c'] =
+// W[co'>>1][c'>>1][(c'&1) - (co'&1) + 1].  The direct form multiplies the two padding frames as zeros: 6 products per
+// (co, c, position) against 4 here -- 1.5x fewer MFMAs, no tensor is copied (the views are free, W' only exists in the packed panel).
+inline bool t2_dense_shape(const zsv_conv_desc* d) {
+    return d->kT == 3 && d->kH == 1 && d->kW == 1 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 1 && d->pH == 0 &&
+           d->pW == 0 && d->Ti == 2 && d->To == 2 && d->Cin >= 16 && d->Cout >= 16;
+}
+inline zsv_conv_desc t2_dense_desc(const zsv_conv_desc* d) {
+    zsv_conv_desc e = *d;
+    e.Cin = 2 * d->Cin; e.Cout = 2 * d->Cout;
+    e.Ti = e.To = 1; e.kT = 1; e.pT = 0;
+    return e;
+}
+// element offset in W[Cout][cin][3] of the dense weight (row, col) = (co', c')
+__host__ __device__ inline long t2_weight_offset(int co2, int c2, int cin) {
+    return ((long)(co2 >> 1) * cin + (c2 >> 1)) * 3 + ((c2 & 1) - (co2 & 1) + 1);
+}
 
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
 

@@ -30,6 +30,8 @@
 
 namespace zsv {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct Magic { unsigned mul, shift; };     // q = (umulhi(p, mul) + p) >> shift, exact for p < 2^31
 static Magic make_magic(unsigned d) {
     Magic m;
@@ -350,7 +352,63 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     }
 }
 
+// The same sum for FEW slices and a large slab (the small-voxel layers: 2-4 slices of a 17-21 MB gradient): one block per
+// output channel reads its [taps][Cpad] row of every slice with 16-byte loads (coalesced), adds the slices in order -- the
+// order slab_sum_kernel uses for up to 8 slices, so the bits are the same -- and writes dw[co][ci][tap] through an LDS
+// transpose as whole contiguous rows (slab_sum_kernel's 4-byte writes at stride `taps` made it run at 1 TB/s).
+__global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                            int M, int Cin, int taps, int Cpad, int slices) {
+    extern __shared__ __attribute__((aligned(16))) float row[];          // [taps][Cpad]
+    const int co = blockIdx.x;
+    const int len = taps * Cpad;                                        // (Cpad % 16 == 0: whole float4s)
+    const size_t slab = (size_t)M * len;
+    const float* src = slabs + (size_t)co * len;
+    for (int i = 4 * (int)threadIdx.x; i < len; i += 1024) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(src + i);
+        for (int k = 1; k < slices; ++k) t += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab + i);
+        *reinterpret_cast<f32x4*>(row + i) = t;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)co * Cin * taps;
+    const int n = Cin * taps;
+    for (int o = (int)threadIdx.x; o < n; o += 256) {
+        const int ci = o / taps, tap = o - ci * taps;
+        dst[o] = row[tap * Cpad + ci];
+    }
+}
+
+// launches the slab sum that fits the geometry (same result bits either way)
+int slab_sum(const float* slabs, float* dw, int M, int Cin, int taps, int Cpad, int slices, hipStream_t stream) {
+    const size_t row_bytes = (size_t)taps * Cpad * sizeof(float);
+    if (slices <= 8 && row_bytes <= 64 * 1024 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && !ZSV_KNOB(NO_SLAB_SUM_ROWS)) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)slab_sum_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (attr != hipSuccess) return ZSV_E_LAUNCH;
+        hipLaunchKernelGGL(slab_sum_rows_kernel, dim3((unsigned)M), dim3(256), row_bytes, stream, slabs, dw, M, Cin, taps, Cpad, slices);
+        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+    }
+    const long n = (long)M * taps * Cpad;
+    long blocks = (n + 31) / 32;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, dw, M, Cin, taps, Cpad, slices);
+    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+}
+
 static int wgrad_bp() { return 32; }
+
+// the dense gradient dW'[2 Cout][2 Cin] of a two-frame temporal convolution (conv_params.h: t2_dense_shape) folded back
+// onto its three taps: kt = ti - to + 1, so tap 0 <- (to 1, ti 0), tap 1 <- (0, 0) + (1, 1), tap 2 <- (0, 1)
+__global__ __launch_bounds__(256) void t2_fold_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int Cout, int Cin) {
+    const long n = (long)Cout * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long co = i / Cin, c = i - co * Cin;
+        const float* r0 = dw2 + (2 * co) * (2L * Cin) + 2 * c;          // row (co, to = 0): columns (c, ti = 0), (c, ti = 1)
+        const float* r1 = r0 + 2L * Cin;                               // row (co, to = 1)
+        const f32x2 a = *reinterpret_cast<const f32x2*>(r0), b = *reinterpret_cast<const f32x2*>(r1);
+        dw[3 * i] = b[0];
+        dw[3 * i + 1] = a[0] + b[1];
+        dw[3 * i + 2] = a[1];
+    }
+}
 
 struct WgradPlan {
     int cfg;        // 0: 144x128, 1: 128x128, 2: 64x128, 3: 80x128
@@ -451,8 +509,15 @@ static bool wgrad_two_taps(int taps, int nblk, int bn) {
 
 using namespace zsv;
 
+static bool t2_dense(const zsv_conv_desc* d) { return t2_dense_shape(d) && !ZSV_KNOB(NO_T2_DENSE); }
+static size_t t2_dw_bytes(const zsv_conv_desc* d) { return ((size_t)4 * d->Cout * d->Cin * sizeof(float) + 255) & ~(size_t)255; }
+
 extern "C" size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d) {
     if (conv_check(d) != ZSV_OK) return 0;
+    if (t2_dense(d)) {                  // [dense gradient dW'] [workspace of the dense 1x1x1 problem]
+        const zsv_conv_desc d2 = t2_dense_desc(d);
+        return t2_dw_bytes(d) + zsv_conv3d_wgrad_workspace_bytes(&d2);
+    }
     if (d->Cin < 16) return wgrad_generic_workspace_bytes(d);
     const WgradPlan pl = wgrad_plan(d);
     size_t need = (size_t)pl.slices * d->Cout * pl.Kp * sizeof(float);
@@ -487,6 +552,18 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     if (st) return st;
     if (!x || !dy || !dw) return ZSV_E_NULL;
     hipStream_t stream = (hipStream_t)stream_;
+    if (t2_dense(d)) {
+        const zsv_conv_desc d2 = t2_dense_desc(d);
+        const size_t head = t2_dw_bytes(d);
+        if (!workspace || workspace_bytes < head + zsv_conv3d_wgrad_workspace_bytes(&d2)) return ZSV_E_WORKSPACE;
+        float* dw2 = (float*)workspace;
+        st = zsv_conv3d_wgrad(&d2, x, dy, dw2, (char*)workspace + head, workspace_bytes - head, stream_);
+        if (st) return st;
+        long blocks = ((long)d->Cout * d->Cin + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(t2_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dw2, dw, d->Cout, d->Cin);
+        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+    }
     if (d->Cin < 16) return wgrad_generic(d, x, dy, dw, workspace, workspace_bytes, stream);
     const WgradPlan pl = wgrad_plan(d);
     const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
@@ -497,13 +574,7 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
         int slices = 0, cpad = 0;
         st = wgrad_dma(d, x, dy, workspace, workspace_bytes, &slices, &cpad, stream);
         if (st) return st;
-        const int taps = d->kT * d->kH * d->kW;
-        const long n = (long)d->Cout * taps * cpad;
-        long blocks = (n + 31) / 32;
-        if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, d->Cout,
-                           d->Cin, taps, cpad, slices);
-        return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+        return slab_sum((const float*)workspace, dw, d->Cout, d->Cin, d->kT * d->kH * d->kW, cpad, slices, stream);
     }
 
     WgradParams p;
@@ -542,12 +613,7 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
         default: wgrad_launch<5, 2, 1, 4>(p, av4, twotap, grid, stream, x, dy, out, pl.tiles_m, tiles_mn); break;
     }
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
-    const long n = (long)p.M * p.taps * pl.Cpad;
-    long blocks = (n + 31) / 32;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, dw, p.M,
-                       p.Cin, p.taps, pl.Cpad, pl.slices);
-    return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
+    return slab_sum((const float*)workspace, dw, p.M, p.Cin, p.taps, pl.Cpad, pl.slices, stream);
 }
 
 extern "C" size_t zsv_linear_wgrad_workspace_bytes(int32_t rows, int32_t in_features, int32_t out_features) {

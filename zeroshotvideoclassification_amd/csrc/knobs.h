@@ -50,7 +50,10 @@
     X(NO_WINO_FWD) \
     X(WINO_NO_F43) \
     X(WINOT_NO_F43) \
-    X(WINO_NO_X4)
+    X(WINO_NO_X4) \
+    X(NO_SLAB_SUM_ROWS) \
+    X(NO_PACK_TILED) \
+    X(NO_T2_DENSE)
 
 namespace zsv {
 enum KnobId {
