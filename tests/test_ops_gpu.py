@@ -24,10 +24,21 @@ def close(a, ref, rtol=2e-5, what=""):
     assert err <= rtol * scale + 1e-12, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
 
 
+def uses_f43(w):
+    """F(4,3) along W: W % 4 == 0, or a row that nearly fills a power-of-two virtual row of 8 / 16 / 32 / 64 voxels
+    (conv_wino.hip wino_vw_width: 7, 14, 15, 29-31, 61-63)."""
+    if w % 4 == 0:
+        return True
+    for wv in (8, 16, 32, 64):
+        if w < wv:
+            return w > wv - 4 and 8 * w >= 7 * wv
+    return False
+
+
 def wino_vs_direct_tol(w):
-    """The kw taps run in Winograd form: F(4,3) when W % 4 == 0 (transform constants up to 8: measured <= 6e-6 of the
+    """The kw taps run in Winograd form: F(4,3) when `uses_f43` (transform constants up to 8: measured <= 6e-6 of the
     output range from the direct kernel, K up to 6912), F(2,3) otherwise (<= 2e-6)."""
-    return 1e-5 if w % 4 == 0 else 5e-6
+    return 1e-5 if uses_f43(w) else 5e-6
 
 
 CONV_CASES = [
@@ -1179,3 +1190,102 @@ def test_tiled_weight_pack_equals_the_elementwise_pack(monkeypatch):
             assert torch.equal(u, v), (xs, ws)
         ref = F.conv3d(x.double().cpu(), w.double().cpu(), stride=stride, padding=pad)
         close(a[0], ref, what=f"forward {ws}")
+
+
+VW_CASES = [
+    # name, N, Cin, Cout, kT, (T, H, W)
+    ("layer4_7x7", 22, 512, 921, 1, (2, 7, 7)),            # S9: 2464 virtual voxels, K parts
+    ("layer4_dgrad_rows", 22, 921, 512, 1, (2, 7, 7)),
+    ("layer3_14x14", 22, 256, 460, 1, (4, 14, 14)),         # S6
+    ("w15_small", 3, 32, 40, 1, (3, 9, 15)),               # one real voxel short of the virtual row; partial last tile
+    ("w30", 2, 24, 48, 1, (2, 11, 30)),
+    ("w62", 2, 16, 32, 1, (1, 9, 62)),
+    ("c3d_conv5_like_333", 6, 64, 80, 3, (2, 7, 7)),       # 9 row taps, temporal padding
+    ("r3d_layer3_333", 8, 48, 64, 3, (4, 14, 14)),
+]
+
+
+@pytest.mark.parametrize("case", VW_CASES, ids=[c[0] for c in VW_CASES])
+def test_conv3d_winograd_virtual_width(case, monkeypatch):
+    """Row lengths that are not a multiple of 4 (layer3's 14, layer4's 7, resnet.py:217-220) run the F(4,3) kernel on rows
+    padded -- virtually -- to 8 / 16 / 32 / 64 voxels (conv_wino4_kernel VW): forward (plain, + BatchNorm partial statistics, +
+    bias + residual + ReLU) and input gradient (plain, + shortcut gradient) against torch CPU fp64 and against the kernels the
+    geometry used before (ZSV_WINO_NO_VW=1: F(2,3) for even W, the direct kernel for odd W)."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    name, n, cin, cout, kt, (t, h, w) = case
+    assert uses_f43(w) and w % 4 != 0
+    g = torch.Generator().manual_seed(len(name) * 131 + cin)
+    k, pad = (kt, 3, 3), (kt // 2, 1, 1)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * 9 * kt)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, t, h, w, generator=g)
+    dy = torch.randn(n, cout, t, h, w, generator=g)
+    add = torch.randn(n, cin, t, h, w, generator=g)
+    lib = _lib.load()
+    d = ops.conv_desc(x.shape, wt.shape, 1, pad)
+    xd, wd, bd, rd, dyd, addd = (v.to(DEV) for v in (x, wt, bias, res, dy, add))
+    big = n * cin * t * h * w * cout > 2e9                  # fp64 CPU reference on two clips only
+    clips = [0, n - 1] if big else list(range(n))
+
+    def fwd(mode):
+        y = torch.full((n, cout, t, h, w), float("nan"), device=DEV)
+        nbytes = lib.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        stats, tiles = None, 0
+        if mode == "stats":
+            tiles = lib.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr())
+            if tiles <= 0:
+                return None, None
+            stats = torch.full((2, cout, tiles), float("nan"), device=DEV)
+        full = mode == "full" and lib.zsv_conv3d_fwd_add_supported(ctypes.byref(d))
+        if mode == "full" and not full:
+            return None, None
+        _lib.check(lib.zsv_conv3d_fwd_full(ctypes.byref(d), xd.data_ptr(), wd.data_ptr(), bd.data_ptr() if full else None,
+                                           rd.data_ptr() if full else None, y.data_ptr(), 1 if full else 0,
+                                           stats.data_ptr() if stats is not None else None, tiles, ws.data_ptr(), nbytes, None), "fwd")
+        torch.cuda.synchronize()
+        return y, stats
+
+    def dgrad(with_add):
+        if with_add and not lib.zsv_conv3d_dgrad_add_supported(ctypes.byref(d)):
+            return None
+        dx = torch.full((n, cin, t, h, w), float("nan"), device=DEV)
+        nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.zsv_conv3d_dgrad_add(ctypes.byref(d), dyd.data_ptr(), wd.data_ptr(), addd.data_ptr() if with_add else None,
+                                            dx.data_ptr(), ws.data_ptr(), nbytes, None), "dgrad")
+        torch.cuda.synchronize()
+        return dx
+
+    ref = {i: F.conv3d(x[i:i + 1].double(), wt.double(), padding=pad) for i in clips}
+    y, _ = fwd("plain")
+    assert torch.isfinite(y).all()                          # every real voxel was written (the buffer started as NaN)
+    for i in clips:
+        close(y[i:i + 1], ref[i], what=f"forward clip {i}")
+    assert torch.equal(y, fwd("plain")[0]), "bitwise reproducible"
+    ys, stats = fwd("stats")
+    if ys is not None:                                      # (K parts have no fused statistics)
+        assert torch.equal(ys, y)
+        if not big:
+            full_ref = torch.cat([ref[i] for i in clips])
+            close(stats[0].double().sum(1), full_ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="sum y")
+            close(stats[1].double().sum(1), (full_ref * full_ref).sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="sum y^2")
+    yf, _ = fwd("full")
+    if yf is not None:
+        for i in clips:
+            close(yf[i:i + 1], torch.relu(ref[i] + bias.double().view(1, -1, 1, 1, 1) + res[i:i + 1].double()), what="bias + residual + relu")
+    dx = dgrad(False)
+    assert torch.isfinite(dx).all()
+    for i in clips:
+        close(dx[i:i + 1], torch.nn.grad.conv3d_input((1, cin, t, h, w), wt.double(), dy[i:i + 1].double(), padding=pad), what=f"dgrad clip {i}")
+    dxa = dgrad(True)
+    if dxa is not None:
+        close(dxa, dx.double() + add.double().to(DEV), rtol=1e-6, what="dgrad + shortcut gradient")
+    monkeypatch.setenv("ZSV_WINO_NO_VW", "1")
+    y2, dx2 = fwd("plain")[0], dgrad(False)
+    monkeypatch.delenv("ZSV_WINO_NO_VW")
+    close(y, y2.double(), rtol=1e-5, what="virtual width vs previous kernel, forward")
+    close(dx, dx2.double(), rtol=1e-5, what="virtual width vs previous kernel, dgrad")
+    assert not torch.equal(y, y2) and not torch.equal(dx, dx2), "the two paths should not be the same kernel"

@@ -71,36 +71,82 @@ template <int MT>
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(IgemmParams prm, const float* __restrict__ W,
                                                                  float* __restrict__ Wp, int w_m_stride, int w_c_stride,
                                                                  int Cpad, int Mp, int rows_total) {
-    extern __shared__ float tile[];                       // [taps][16][MT + 1]
+    extern __shared__ float tile[];                       // [taps * 16][MT + 1]: row = tap * 16 + channel-in-block
     constexpr int LD = MT + 1;
+    constexpr int MAXJ = 9;                               // 64-lane passes over a run: 16 * taps <= 432 or MT * taps <= 576
     const int cb = blockIdx.x, m0 = blockIdx.y * MT;
     const int taps = prm.taps;
-    const int n = 16 * MT * taps;
-    const bool c_contig = prm.t2_cin ? prm.dir > 0 : w_c_stride < w_m_stride;        // forward: (c, tap) contiguous for a fixed m
-    for (int e = threadIdx.x; e < n; e += 256) {
-        int ml, cl, tap;
-        if (c_contig) { tap = e % taps; const int r = e / taps; cl = r % 16; ml = r / 16; }
-        else          { tap = e % taps; const int r = e / taps; ml = r % MT; cl = r / MT; }
-        const int m = m0 + ml, c = cb * 16 + cl;
-        float v = 0.f;
-        if (m < prm.M && c < prm.gC && cb * 16 < Cpad) {
-            const int jt = tap / prm.nHW;
-            const int r = tap - jt * prm.nHW;
-            const int jh = r / prm.nW;
-            const int jw = r - jh * prm.nW;
-            const int tap_full = ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
-            v = prm.t2_cin ? W[prm.dir > 0 ? t2_weight_offset(m, c, prm.t2_cin) : t2_weight_offset(c, m, prm.t2_cin)]
-                           : W[(size_t)m * w_m_stride + (size_t)c * w_c_stride + tap_full];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool t2 = prm.t2_cin != 0;
+    const bool c_contig = t2 ? prm.dir > 0 : w_c_stride < w_m_stride;        // forward: (c, tap) contiguous for a fixed m
+    const bool cb_live = cb * 16 < Cpad;
+    auto tap_full = [&](int tap) {
+        const int jt = tap / prm.nHW;
+        const int r = tap - jt * prm.nHW;
+        const int jh = r / prm.nW;
+        const int jw = r - jh * prm.nW;
+        return ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
+    };
+    // The (second index, tap) decomposition of a lane's run elements does not depend on the outer index: done once.
+    if (c_contig) {                                       // a wave per row m; lanes walk the row's (c, tap) run
+        const int run = 16 * taps;
+        int off[MAXJ], dst[MAXJ], cc[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int r = lane + 64 * j;
+            off[j] = -2;                                  // -2: beyond the run, -1: padding (zero)
+            if (r < run) {
+                const int cl = r / taps, tap = r - cl * taps, c = cb * 16 + cl;
+                cc[j] = c;
+                dst[j] = (tap * 16 + cl) * LD;
+                off[j] = (c < prm.gC && cb_live) ? c * w_c_stride + tap_full(tap) : -1;
+            }
         }
-        tile[(tap * 16 + cl) * LD + ml] = v;
+        for (int ml = wave; ml < MT; ml += 4) {
+            const int m = m0 + ml;
+            const float* src = W + (size_t)m * w_m_stride;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                if (off[j] == -2) continue;
+                float v = 0.f;
+                if (off[j] >= 0 && m < prm.M) v = t2 ? W[t2_weight_offset(m, cc[j], prm.t2_cin)] : src[off[j]];
+                tile[dst[j] + ml] = v;
+            }
+        }
+    } else {                                              // a wave per reduction channel c; lanes walk its (m, tap) run
+        const int run = MT * taps;
+        int off[MAXJ], dst[MAXJ], mm[MAXJ];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int r = lane + 64 * j;
+            off[j] = -2;
+            if (r < run) {
+                const int ml = r / taps, tap = r - ml * taps, m = m0 + ml;
+                mm[j] = m;
+                dst[j] = tap * 16 * LD + ml;
+                off[j] = m < prm.M ? m * w_m_stride + tap_full(tap) : -1;
+            }
+        }
+        for (int cl = wave; cl < 16; cl += 4) {
+            const int c = cb * 16 + cl;
+            const float* src = W + (size_t)c * w_c_stride;
+            const bool live = c < prm.gC && cb_live;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                if (off[j] == -2) continue;
+                float v = 0.f;
+                if (off[j] >= 0 && live) v = t2 ? W[t2_weight_offset(c, mm[j], prm.t2_cin)] : src[off[j]];
+                tile[dst[j] + cl * LD] = v;
+            }
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int ml = e % MT;
-        const int r = e / MT;                              // r = tap * 16 + cl
-        const int tap = r / 16, cl = r % 16;
-        const long row = ((long)cb * taps + tap) * 16 + cl;
-        if (row < rows_total && m0 + ml < Mp) Wp[row * Mp + m0 + ml] = tile[r * LD + ml];
+    // rows of MT consecutive m: Wp row = (cb * taps + tap) * 16 + cl = cb * taps * 16 + LDS row
+    const int nrows = taps * 16;
+    const long row0 = (long)cb * nrows;
+    for (int e = threadIdx.x; e < nrows * MT; e += 256) {
+        const int ml = e % MT, r = e / MT;                // (MT is a power of two)
+        if (row0 + r < rows_total && m0 + ml < Mp) Wp[(row0 + r) * Mp + m0 + ml] = tile[r * LD + ml];
     }
 }
 

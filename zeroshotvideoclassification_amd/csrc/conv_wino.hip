@@ -40,6 +40,7 @@ struct WinoParams {
     int S, HW, W, H, T;     // voxels per clip / frame, row length, rows, frames
     int kT, R;              // temporal taps (1 or 3, pad kT/2), row taps R = 3*kT (a row tap = one (kt, kh))
     int P;                  // N * S
+    int Wv, Pv;             // virtual-width form (conv_wino4_kernel VW): rows padded to Wv = 8 / 16 / 32 / 64 voxels, Pv = N * T * H * Wv
     unsigned in_bytes, u_bytes;   // bytes of the input tensor / of the transformed-weight array
     int tiles_m, tiles_n;
     int ksplit, chunks_per_split;   // > 1: K is cut into parts, part s writes its raw partial result to OUT + s * slab_elems
@@ -390,7 +391,15 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 #ifndef W4ABL
 #define W4ABL 0        // timing-only ablation builds (tools/variant.sh): 1 no DMAs after the first chunk, 2 no fragment reads, 4 no chunk-end wait / barrier, 8 no stores
 #endif
-template <int TM, int NCHUNKS>
+// VW ("virtual width"): rows whose length W is NOT a multiple of 4 (layer3's 14, layer4's 7: resnet.py:217-220 on 112x112 clips)
+// are tiled as if they were Wv = 8 / 16 / 32 / 64 voxels long (W > Wv - 4, so every quad starts inside its row): a column of the
+// tile is a VIRTUAL voxel (row, wv), its 16-byte piece is fetched from the real address of (row, wv) -- only 4-byte aligned, and
+// a row's last piece carries 1-3 values of the next row, which the lane zeroes in registers (`nvalid`) -- and the epilogue stores
+// only the real voxels.  256 % Wv == 0: tiles and the waves' 64-voxel spans begin and end on row boundaries, so no halo voxels
+// exist (d0 of a row's first quad and d5 of its last are the zero padding).  7-wide rows run F(4,3) on 8 columns: 12 multiplies
+// per 7 outputs against 21 (1.75x fewer MFMAs than the direct kernel they used to take); 14-wide rows 24 per 14 against the
+// F(2,3) kernel's 28, with 16-byte image DMAs instead of 4-byte ones.
+template <int TM, int NCHUNKS, bool VW = false>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, const float* __restrict__ Up,
                                                             const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -416,16 +425,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
     const int ch_bytes = 4 * prm.S;
+    // VW: `p` is a virtual voxel (row, wv), row over the N*T*H rows; `sp` = element offset of the real voxel inside its clip
+    auto locate = [&](int p, int& n, int& sp, int& t, int& h, int& wv) -> bool {
+        if constexpr (VW) {
+            if (p < 0 || p >= prm.Pv) return false;
+            const int row = p / prm.Wv;
+            wv = p - row * prm.Wv;
+            n = row / (prm.T * prm.H);
+            const int rr = row - n * (prm.T * prm.H);
+            t = rr / prm.H;
+            h = rr - t * prm.H;
+            sp = rr * prm.W + wv;
+            return true;
+        } else {
+            if (p < 0 || p >= prm.P) return false;
+            n = p / prm.S;
+            sp = p - n * prm.S;
+            t = sp / prm.HW;
+            const int r = sp - t * prm.HW;
+            h = r / prm.W;
+            wv = r - h * prm.W;
+            return true;
+        }
+    };
     auto decode = [&](int p, int& base_bytes, unsigned& hmask) {
         base_bytes = 0;
         hmask = 0;
-        if (p >= 0 && p < prm.P) {
-            const int n = p / prm.S;
-            int r = p - n * prm.S;
-            const int t = r / prm.HW;
-            r -= t * prm.HW;
-            const int h = r / prm.W;
-            base_bytes = 4 * (n * prm.C * prm.S + (p - n * prm.S));
+        int n, sp, t, h, wv;
+        if (locate(p, n, sp, t, h, wv)) {
+            base_bytes = 4 * (n * prm.C * prm.S + sp);
             for (int kt = 0; kt < prm.kT; ++kt)
                 for (int kh = 0; kh < 3; ++kh)
                     hmask |= (unsigned)((unsigned)(h + kh - 1) < (unsigned)prm.H && (unsigned)(t + kt - prm.kT / 2) < (unsigned)prm.T) << (kt * 3 + kh);
@@ -433,10 +461,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     };
     int base_bytes;
     unsigned hmask;
-    decode(n0 + 4 * lane, base_bytes, hmask);             // this lane's 16-byte piece of every k row (W % 4 == 0: one row, one bit)
+    decode(n0 + 4 * lane, base_bytes, hmask);             // this lane's 16-byte piece of every k row (one row, one bit)
     int halo_base = 0;
     unsigned halo_mask = 0;
-    if (wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
+    if (!VW && wave == 0) decode((lane & 1) ? n0 + BN : n0 - 1, halo_base, halo_mask);
 
     // U panels: 6*TM pieces of 16 rows x 64 B, piece q = wave + 4*j = (point q / TM, row block q % TM)
     constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0), 16, (int)(ci < prm.C ? voff : OOB16),
                                                      ci < prm.C ? ci * ch_bytes : 0, 0, 0);
         }
-        if (wave == 0) {
+        if (!VW && wave == 0) {
             const int k = lane >> 1;
             const int ci = ci0 + k;
             const unsigned hok = (halo_mask >> ld_r) & 1u;
@@ -486,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         }
     };
     auto place_halo = [&](int buf) {
-        if (wave == 0 && lane < 32) {
+        if (!VW && wave == 0 && lane < 32) {
             float* bs = img_of(buf);
             const float v = bs[B_FLOATS + lane];
             bs[(lane >> 1) * LDB + ((lane & 1) ? C0 + BN : C0 - 1)] = v;
@@ -500,8 +528,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int g = lane >> 4, r16 = lane & 15;
-    const int v_first = n0 + 64 * wave + 4 * r16;                  // first voxel of this lane's quad
-    const bool zero_d0 = v_first % prm.W == 0, zero_d5 = v_first % prm.W + 4 >= prm.W;
+    const int v_first = n0 + 64 * wave + 4 * r16;                  // first (virtual) voxel of this lane's quad
+    const int w_first = v_first % (VW ? prm.Wv : prm.W);
+    const bool zero_d0 = w_first == 0, zero_d5 = w_first + 4 >= prm.W;
+    const int nvalid = VW ? prm.W - w_first : 4;                    // VW: real voxels of the quad (1..4 at a row's end; W > Wv - 4)
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
 
     issue(c_first, 0);
@@ -538,7 +568,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int sl = s & 1;
-            const float d1 = dm[sl][0], d2 = dm[sl][1], d3 = dm[sl][2], d4 = dm[sl][3];
+            const float d1 = dm[sl][0];
+            float d2 = dm[sl][1], d3 = dm[sl][2], d4 = dm[sl][3];
+            if constexpr (VW) {                              // the tail of a row's last piece belongs to the next row
+                d2 = nvalid < 2 ? 0.f : d2;
+                d3 = nvalid < 3 ? 0.f : d3;
+                d4 = nvalid < 4 ? 0.f : d4;
+            }
             const float dl = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(de[sl]), __float_as_int(d4), 0x111, 0xf, 0xf, false));   // row_shr:1
             const float dr = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(de[sl]), __float_as_int(d1), 0x101, 0xf, 0xf, false));   // row_shl:1
             const float d0 = zero_d0 ? 0.f : dl, d5 = zero_d5 ? 0.f : dr;
@@ -576,9 +612,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     const bool stats = prm.stat_sum != nullptr;
     float* red = pool;                                   // [4 waves][BM][2] partial sums (the staging LDS is free now)
     if (stats) __syncthreads();
-    const bool quad_ok = v_first < prm.P;
-    const int n_clip = v_first / prm.S;
-    const int quad_off = n_clip * prm.M * prm.S + (v_first - n_clip * prm.S);
+    int n_clip = 0, sp_first = 0;
+    bool quad_ok;
+    {
+        int t_, h_, wv_;
+        quad_ok = locate(v_first, n_clip, sp_first, t_, h_, wv_);
+    }
+    const int quad_off = n_clip * prm.M * prm.S + sp_first;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -589,13 +629,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             f32x4 y = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
             float s1 = 0.f, s2 = 0.f;
             if (quad_ok && m < prm.M) {
-                s1 = (y[0] + y[1]) + (y[2] + y[3]);
-                s2 = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
                 const int off = quad_off + m * prm.S;
-                if (prm.add != nullptr) y += *reinterpret_cast<const f32x4*>(prm.add + off);
-                if (prm.bias != nullptr) y += prm.bias[m];
-                if (prm.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
-                *reinterpret_cast<f32x4*>(OUT + off) = y;
+                if (!VW || nvalid >= 4) {
+                    s1 = (y[0] + y[1]) + (y[2] + y[3]);
+                    s2 = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+                    if (prm.add != nullptr) y += *reinterpret_cast<const f32x4*>(prm.add + off);      // (VW: 4-byte aligned 16-byte accesses)
+                    if (prm.bias != nullptr) y += prm.bias[m];
+                    if (prm.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+                    *reinterpret_cast<f32x4*>(OUT + off) = y;
+                } else {                                  // a row's last quad: its first `nvalid` values are real voxels
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        if (e < nvalid) {
+                            float v = y[e];
+                            s1 += v;
+                            s2 += v * v;
+                            if (prm.add != nullptr) v += prm.add[off + e];
+                            if (prm.bias != nullptr) v += prm.bias[m];
+                            if (prm.relu) v = fmaxf(v, 0.f);
+                            OUT[off + e] = v;
+                        }
+                    }
+                }
             }
             if (stats) {                                  // 16 lanes (r16) share row m
 #pragma unroll
@@ -1065,8 +1120,46 @@ static int wino_tm(int M) {
 // K parts: 1 when the tiles alone fill the two-workgroups-per-CU round, else 2..4 parts of >= 12 chunks each that do
 // (their raw partial results go to slabs, summed by splitk_reduce); 0 = too few tiles either way: the direct kernel
 static bool winot_geometry(const zsv_conv_desc* d, int M);
+
+// Virtual-width form of the F(4,3) kernel (conv_wino4_kernel VW): row lengths that are not a multiple of 4 but fill a power-of-two
+// row of 8 / 16 / 32 / 64 voxels to more than Wv - 4 (7, 14, 15, 29-31, 61-63: at most 12.5 % empty columns)
+static int wino_vw_width(const zsv_conv_desc* d) {
+    if (d->Wi % 4 == 0 || ZSV_KNOB(WINO_NO_VW) || ZSV_KNOB(WINO_NO_F43)) return 0;
+    for (int wv = 8; wv <= 64; wv *= 2)
+        if (d->Wi < wv) return d->Wi > wv - 4 && 8 * d->Wi >= 7 * wv ? wv : 0;
+    return 0;
+}
+// rows per workgroup and K parts of a virtual-width launch: the pair with the best (round fill x row padding) over one or two
+// rounds of the 512 resident workgroups, fewer K parts on ties (each part writes a slab).  Returns the K parts (0: none fits).
+static int wino_vw_plan(const zsv_conv_desc* d, int M, int& tm) {
+    const int wv = wino_vw_width(d);
+    const long tiles_n = ((long)d->N * d->Ti * d->Hi * wv + 255) / 256;
+    const int C = M == d->Cout ? d->Cin : d->Cout;
+    const long nchunks = (long)((C + 15) / 16) * 3 * d->kT;
+    double best = 0.0;
+    int best_ks = 0;
+    tm = 4;
+    for (int t = 4; t >= 3; --t) {
+        const int bm = 16 * t;
+        const long tiles = ((M + bm - 1) / bm) * tiles_n;
+        const double rows = (double)M / (double)(((M + bm - 1) / bm) * bm);
+        for (int ks = 1; ks <= 8; ++ks) {
+            if (ks > 1 && (nchunks / ks < 12 || tiles >= 512)) break;      // K parts only below one round of workgroups
+            const long wgs = tiles * ks;
+            if (wgs < 256 || (ks > 1 && wgs > 1024)) continue;
+            // (beyond one round the workgroups backfill: the partial last round costs about a third of what whole rounds would)
+            const double r = (double)wgs / 512.0, rc = (double)((wgs + 511) / 512);
+            const double fill = wgs <= 512 ? r : r / (r + 0.33 * (rc - r));
+            const double eff = rows * fill * (1.0 - 0.03 * (ks - 1));
+            if (eff > best + 1e-9) { best = eff; best_ks = ks; tm = t; }
+        }
+    }
+    return best_ks;
+}
+
 static int wino_ksplit(const zsv_conv_desc* d, int M) {
     if (winot_geometry(d, M)) return 1;
+    if (wino_vw_width(d)) { int tm; return wino_vw_plan(d, M, tm); }
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     const int bm = 16 * wino_tm(M), C = M == d->Cout ? d->Cin : d->Cout;
     const long tiles = ((M + bm - 1) / bm) * ((P + 255) / 256), nchunks = (long)((C + 15) / 16) * 3 * d->kT;
@@ -1108,12 +1201,12 @@ static bool wino_geometry(const zsv_conv_desc* d, int M) {
     if ((d->kT != 1 && d->kT != 3) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT != d->kT / 2 ||
         d->pH != 1 || d->pW != 1)
         return false;
-    if (d->Wi % 2 != 0 || d->Cin < 16 || d->Cout < 16) return false;
+    if ((d->Wi % 2 != 0 && !wino_vw_width(d)) || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     // byte offsets (4 * element index, plus tap shifts) are formed in signed 32-bit registers and the out-of-range
     // sentinels 0xFFFFFFF0 / 0xFFFFFFFF must stay >= the descriptor's num_records: tensors of < 2^29 elements
     // (2 GiB) only, like conv_wgrad_tring; larger ones take the direct kernel.
-    if (P % 2 != 0 || (long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
+    if ((P % 2 != 0 && !wino_vw_width(d)) || (long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
     return wino_ksplit(d, M) > 0;
 }
 
@@ -1122,13 +1215,20 @@ bool wino_dgrad_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->
 bool wino_fwd_applicable(const zsv_conv_desc* d) { return wino_geometry(d, d->Cout) && ZSV_KNOB(NO_WINO_FWD) == nullptr; }
 int wino_fwd_stat_tiles(const zsv_conv_desc* d) {
     if (winot_geometry(d, d->Cout)) return d->N * winot_segs(d);
+    if (const int wv = wino_vw_width(d)) return (int)(((long)d->N * d->Ti * d->Hi * wv + 255) / 256);
     return (int)(((long)d->N * d->Ti * d->Hi * d->Wi + 255) / 256);
 }
 
-// W % 4 == 0: the F(4,3) kernel (6 Winograd points), else F(2,3) (4 points)
-static bool wino_f43(const zsv_conv_desc* d) { return d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_F43) == nullptr; }
+// W % 4 == 0 (or a virtual width): the F(4,3) kernel (6 Winograd points), else F(2,3) (4 points)
+static bool wino_f43(const zsv_conv_desc* d) { return (d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_F43) == nullptr) || wino_vw_width(d) != 0; }
+// rows per workgroup of this launch (16 * tm)
+static int wino_tm_for(const zsv_conv_desc* d, int M) {
+    int tm = wino_tm(M);
+    if (!winot_geometry(d, M) && wino_vw_width(d)) wino_vw_plan(d, M, tm);
+    return tm;
+}
 static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
-    const int bm = 16 * wino_tm(M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
+    const int bm = 16 * wino_tm_for(d, M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
     if (winot_shape(d)) return wino_align((size_t)nblk * 6 * 16 * Mp * sizeof(float));            // (no row taps; 6 points: the F(4,3) form, the F(2,3) form uses 4)
     const int points = wino_f43(d) ? 6 : 4;
     return wino_align((size_t)nblk * 3 * d->kT * points * 16 * Mp * sizeof(float));
@@ -1155,14 +1255,14 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
     return launch_status();
 }
 
-template <int TM, int NCHUNKS>
+template <int TM, int NCHUNKS, bool VW = false>
 static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 272 + 64;                           // as in the kernel
     constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
-    hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS, VW>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
 
@@ -1230,7 +1330,7 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     float* const final_out = out;
     if (!workspace || workspace_bytes < wino_total_bytes(d, M, C)) return ZSV_E_WORKSPACE;
-    const int tm = wino_tm(M), bm = 16 * tm;
+    const int tm = wino_tm_for(d, M), bm = 16 * tm;
     const int ks = wino_ksplit(d, M);
     if (ks < 1) return ZSV_E_UNSUPPORTED;
     if (ks > 1 && (add != nullptr || stat_sum != nullptr)) return ZSV_E_UNSUPPORTED;
@@ -1244,7 +1344,9 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     p.P = d->N * p.S;
     p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
     p.tiles_m = p.Mp / bm;
-    p.tiles_n = (p.P + 255) / 256;
+    p.Wv = wino_vw_width(d);
+    p.Pv = p.Wv ? d->N * d->Ti * d->Hi * p.Wv : p.P;
+    p.tiles_n = (p.Pv + 255) / 256;
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.ksplit = ks;
     p.chunks_per_split = (p.nblk * p.R + ks - 1) / ks;
@@ -1262,7 +1364,9 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const bool x4 = d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_X4) == nullptr;
     int st;
-    if (f43) {
+    if (p.Wv) {
+        st = tm == 3 ? wino4_launch<3, 0, true>(p, up, in, out, stream) : wino4_launch<4, 0, true>(p, up, in, out, stream);
+    } else if (f43) {
         if (tm == 3) st = (p.nblk * p.R == 12 && ks == 1) ? wino4_launch<3, 12>(p, up, in, out, stream) : wino4_launch<3, 0>(p, up, in, out, stream);
         else st = wino4_launch<4, 0>(p, up, in, out, stream);
     } else if (tm == 3) {

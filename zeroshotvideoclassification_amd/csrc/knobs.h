@@ -53,7 +53,8 @@
     X(WINO_NO_X4) \
     X(NO_SLAB_SUM_ROWS) \
     X(NO_PACK_TILED) \
-    X(NO_T2_DENSE)
+    X(NO_T2_DENSE) \
+    X(WINO_NO_VW)
 
 namespace zsv {
 enum KnobId {
