@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--shapes", default="S1,T1")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--pre", action="store_true",
+                    help="forward / wgrad through the BatchNorm-folded entry points (zsv_conv3d_fwd_pre / _wgrad_pre: the kernels a "
+                         "training step runs for the stride-1 temporal convolutions) where the geometry supports them")
     ap.add_argument("--markers", action="store_true",
                     help="launch a one-element fill kernel in front of every (shape, kind) group: tools/kernel_breakdown.py splits a "
                          "rocprofv3 kernel trace of this run at those markers")
@@ -89,6 +92,13 @@ def main():
             "dgrad": lambda: lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), wsf.data_ptr(), nd, stream),
             "wgrad": lambda: lib.zsv_conv3d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, stream),
         }
+        if args.pre and lib.zsv_conv3d_pre_supported(ctypes.byref(d)):
+            pitch = (cin + 15) // 16 * 16
+            coef = torch.zeros(2, pitch, device=dev)
+            coef[0, :cin] = 1.0 + 0.1 * torch.randn(cin, device=dev)
+            coef[1, :cin] = 0.1 * torch.randn(cin, device=dev)
+            calls["fwd"] = lambda: lib.zsv_conv3d_fwd_pre(ctypes.byref(d), x.data_ptr(), coef.data_ptr(), pitch, wt.data_ptr(), y.data_ptr(), None, 0, wsf.data_ptr(), nf, stream)
+            calls["wgrad"] = lambda: lib.zsv_conv3d_wgrad_pre(ctypes.byref(d), x.data_ptr(), coef.data_ptr(), pitch, dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, stream)
         for kind in args.kinds.split(","):
             fn = calls[kind]
             if args.markers:

@@ -67,13 +67,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, cons
 // [16-channel block] x [MT output rows] tile with all its taps: it reads W along whichever of its two axes is contiguous
 // (forward: (c, tap) runs of 16*taps floats per row m; gradient: (m, tap) runs per channel c), parks the tile in LDS as
 // [tap][c][m] and writes Wp rows of MT consecutive m.  Same values, same layout.
-template <int MT>
+template <int MT, int JN>       // JN: 64-lane passes over a run (16 * taps <= 64 JN and MT * taps <= 64 JN)
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(IgemmParams prm, const float* __restrict__ W,
                                                                  float* __restrict__ Wp, int w_m_stride, int w_c_stride,
                                                                  int Cpad, int Mp, int rows_total) {
     extern __shared__ float tile[];                       // [taps * 16][MT + 1]: row = tap * 16 + channel-in-block
     constexpr int LD = MT + 1;
-    constexpr int MAXJ = 9;                               // 64-lane passes over a run: 16 * taps <= 432 or MT * taps <= 576
     const int cb = blockIdx.x, m0 = blockIdx.y * MT;
     const int taps = prm.taps;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,58 +86,69 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(IgemmParams prm
         const int jw = r - jh * prm.nW;
         return ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
     };
-    // The (second index, tap) decomposition of a lane's run elements does not depend on the outer index: done once.
+    // The (second index, tap) decomposition of a lane's run elements does not depend on the outer index: done once.  All loads
+    // of a wave's share are issued before the first LDS store (the kernel is a latency chain otherwise).
+    int off[JN], dst[JN], idx[JN];                        // off: -2 beyond the run, -1 padding (zero), else element offset
     if (c_contig) {                                       // a wave per row m; lanes walk the row's (c, tap) run
         const int run = 16 * taps;
-        int off[MAXJ], dst[MAXJ], cc[MAXJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < JN; ++j) {
             const int r = lane + 64 * j;
-            off[j] = -2;                                  // -2: beyond the run, -1: padding (zero)
+            off[j] = -2; dst[j] = 0; idx[j] = 0;
             if (r < run) {
                 const int cl = r / taps, tap = r - cl * taps, c = cb * 16 + cl;
-                cc[j] = c;
+                idx[j] = c;
                 dst[j] = (tap * 16 + cl) * LD;
                 off[j] = (c < prm.gC && cb_live) ? c * w_c_stride + tap_full(tap) : -1;
             }
         }
-        for (int ml = wave; ml < MT; ml += 4) {
-            const int m = m0 + ml;
+        constexpr int RW = MT / 4;                        // rows per wave
+        float v[RW][JN];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            const int m = m0 + wave + 4 * u;
             const float* src = W + (size_t)m * w_m_stride;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                if (off[j] == -2) continue;
-                float v = 0.f;
-                if (off[j] >= 0 && m < prm.M) v = t2 ? W[t2_weight_offset(m, cc[j], prm.t2_cin)] : src[off[j]];
-                tile[dst[j] + ml] = v;
+            for (int j = 0; j < JN; ++j) {
+                v[u][j] = 0.f;
+                if (off[j] >= 0 && m < prm.M) v[u][j] = t2 ? W[t2_weight_offset(m, idx[j], prm.t2_cin)] : src[off[j]];
             }
         }
+#pragma unroll
+        for (int u = 0; u < RW; ++u)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+                if (off[j] != -2) tile[dst[j] + wave + 4 * u] = v[u][j];
     } else {                                              // a wave per reduction channel c; lanes walk its (m, tap) run
         const int run = MT * taps;
-        int off[MAXJ], dst[MAXJ], mm[MAXJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < JN; ++j) {
             const int r = lane + 64 * j;
-            off[j] = -2;
+            off[j] = -2; dst[j] = 0; idx[j] = 0;
             if (r < run) {
                 const int ml = r / taps, tap = r - ml * taps, m = m0 + ml;
-                mm[j] = m;
+                idx[j] = m;
                 dst[j] = tap * 16 * LD + ml;
                 off[j] = m < prm.M ? m * w_m_stride + tap_full(tap) : -1;
             }
         }
-        for (int cl = wave; cl < 16; cl += 4) {
-            const int c = cb * 16 + cl;
+        float v[4][JN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cl = wave + 4 * u, c = cb * 16 + cl;
             const float* src = W + (size_t)c * w_c_stride;
             const bool live = c < prm.gC && cb_live;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j) {
-                if (off[j] == -2) continue;
-                float v = 0.f;
-                if (off[j] >= 0 && live) v = t2 ? W[t2_weight_offset(c, mm[j], prm.t2_cin)] : src[off[j]];
-                tile[dst[j] + cl * LD] = v;
+            for (int j = 0; j < JN; ++j) {
+                v[u][j] = 0.f;
+                if (off[j] >= 0 && live) v[u][j] = t2 ? W[t2_weight_offset(c, idx[j], prm.t2_cin)] : src[off[j]];
             }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+                if (off[j] != -2) tile[dst[j] + (wave + 4 * u) * LD] = v[u][j];
     }
     __syncthreads();
     // rows of MT consecutive m: Wp row = (cb * taps + tap) * 16 + cl = cb * taps * 16 + LDS row
@@ -557,13 +567,13 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     const int rows_total = prm.taps * Cpad + 16;
     if ((long)prm.M * prm.gC * prm.taps >= 65536 && prm.taps <= 27 && !ZSV_KNOB(NO_PACK_TILED)) {
         // (+1 channel block: the 16 trailing zero rows; c >= gC packs zeros)
-        const int mt = prm.taps <= 9 ? 64 : 16;
+        const int mt = prm.taps <= 9 ? 32 : 16;
         const dim3 grid((unsigned)(nblk + 1), (unsigned)((Mp + mt - 1) / mt));
         const size_t lds = (size_t)prm.taps * 16 * (mt + 1) * sizeof(float);
-        if (mt == 64)
-            hipLaunchKernelGGL((pack_weights_tiled_kernel<64>), grid, dim3(256), lds, stream, prm, W, Wp, w_m_stride, w_c_stride, Cpad, Mp, rows_total);
+        if (mt == 32)
+            hipLaunchKernelGGL((pack_weights_tiled_kernel<32, 5>), grid, dim3(256), lds, stream, prm, W, Wp, w_m_stride, w_c_stride, Cpad, Mp, rows_total);
         else
-            hipLaunchKernelGGL((pack_weights_tiled_kernel<16>), grid, dim3(256), lds, stream, prm, W, Wp, w_m_stride, w_c_stride, Cpad, Mp, rows_total);
+            hipLaunchKernelGGL((pack_weights_tiled_kernel<16, 7>), grid, dim3(256), lds, stream, prm, W, Wp, w_m_stride, w_c_stride, Cpad, Mp, rows_total);
     } else {
         long pb = (total + 255) / 256;
         if (pb > 4096) pb = 4096;

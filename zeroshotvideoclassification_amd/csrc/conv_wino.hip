@@ -1136,6 +1136,8 @@ static int wino_vw_plan(const zsv_conv_desc* d, int M, int& tm) {
     const long tiles_n = ((long)d->N * d->Ti * d->Hi * wv + 255) / 256;
     const int C = M == d->Cout ? d->Cin : d->Cout;
     const long nchunks = (long)((C + 15) / 16) * 3 * d->kT;
+    const char* e = ZSV_KNOB(WINO_VW_MIN_WGS);
+    const long min_wgs = e ? atol(e) : 256;               // fewer workgroups than that: the direct / F(2,3) kernels (tests lower it)
     double best = 0.0;
     int best_ks = 0;
     tm = 4;
@@ -1146,7 +1148,7 @@ static int wino_vw_plan(const zsv_conv_desc* d, int M, int& tm) {
         for (int ks = 1; ks <= 8; ++ks) {
             if (ks > 1 && (nchunks / ks < 12 || tiles >= 512)) break;      // K parts only below one round of workgroups
             const long wgs = tiles * ks;
-            if (wgs < 256 || (ks > 1 && wgs > 1024)) continue;
+            if (wgs < min_wgs || (ks > 1 && wgs > 1024)) continue;
             // (beyond one round the workgroups backfill: the partial last round costs about a third of what whole rounds would)
             const double r = (double)wgs / 512.0, rc = (double)((wgs + 511) / 512);
             const double fill = wgs <= 512 ? r : r / (r + 0.33 * (rc - r));

@@ -54,7 +54,8 @@
     X(NO_SLAB_SUM_ROWS) \
     X(NO_PACK_TILED) \
     X(NO_T2_DENSE) \
-    X(WINO_NO_VW)
+    X(WINO_NO_VW) \
+    X(WINO_VW_MIN_WGS)
 
 namespace zsv {
 enum KnobId {
