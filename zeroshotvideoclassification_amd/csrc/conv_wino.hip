@@ -53,6 +53,8 @@ struct WinoParams {
     // temporal form (conv_winot_kernel): PW = 256 / T positions per tile, segs = tiles per clip; PRE: the input is read as
     // relu(in * scale[c] + shift[c]) with pre_coef = [2][pre_pitch] (see conv_tap.hip PRE / zsv_bn_fwd_train_coeffs)
     int PW, segs;
+    int pw_log2;            // log2(PW) (PW = 256 / T is 16, 32 or 64)
+    unsigned out_bytes;     // bytes of the produced tensor (buffer-addressed stores of the temporal F(4,3) kernel)
     const float* pre_coef;
     int pre_pitch;
 };
@@ -905,7 +907,13 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
 // T frames of PW = 256 / T positions, [16 k][T][PW], no halo: frames -1 and T..T+3 are a wave-uniform zeroing of d0 / d5); 64 frame
 // QUADS per workgroup, one 16-quad block (16 positions of one quad) per wave, six accumulator sets.  At 64 rows the six U panels are
 // single-buffered (a second barrier per chunk, as conv_wino4_kernel) so that two workgroups fit a CU.
-template <int TM, bool PRE>
+// EPI selects the epilogue at compile time: 0 = plain stores (the input gradients), 1 = + BatchNorm partial statistics (the
+// training forward), 2 = run-time add / bias / ReLU (+ statistics) (inference engine, shortcut gradients).  With K = 64 .. 144
+// channels these kernels run 4 - 9 chunks per tile, so what surrounds the chunk loop counts: the run-time-flag epilogue compiled to
+// ~130 instructions and five branches per output row (1 480 vector instructions per wave against 288 MFMAs on the layer1 dgrad,
+// profiles/r03_t1_pmc.json); EPI 0 / 1 are branch-free: buffer stores whose row / frame offsets are scalar, out-of-range lanes
+// dropped by the descriptor's range check, 16-lane DPP sums for the statistics.
+template <int TM, bool PRE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, const float* __restrict__ Up,
                                                              const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -927,12 +935,12 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     const int ct = tile / prm.tiles_m;                          // column tile = (clip, position segment)
     const int n_img = ct / prm.segs, pos0 = (ct - n_img * prm.segs) * prm.PW;
     const int T = prm.T, PW = prm.PW, HW = prm.HW;
-    const int pq = PW >> 2;                                     // 16-byte pieces per frame row
+    const int pq_log2 = prm.pw_log2 - 2;                        // 16-byte pieces per frame row: PW / 4 (a power of two)
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
     const int ch_bytes = 4 * prm.S;
     // this lane's 16-byte piece of every k row: frame lane / pq, positions pos0 + 4 * (lane % pq) ..
-    const int pf = lane / pq, pp = pos0 + 4 * (lane - pf * pq);
+    const int pf = lane >> pq_log2, pp = pos0 + 4 * (lane - (pf << pq_log2));
     const unsigned piece_off = pp < HW ? (unsigned)(4 * (n_img * prm.C * prm.S + pf * HW + pp)) : OOB16;
 
     constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
@@ -980,9 +988,9 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
 
     const int g = lane >> 4, r16 = lane & 15;
     // this wave's 16-quad block: block b = wave = (frame quad b / (PW/16), 16-position group b % (PW/16))
-    const int groups = PW >> 4;
-    const int tq = wave / groups;
-    const int col = 16 * (wave - tq * groups) + r16;               // position inside the tile
+    const int groups_log2 = prm.pw_log2 - 4;                       // 16-position groups per frame: PW / 16
+    const int tq = wave >> groups_log2;
+    const int col = 16 * (wave - (tq << groups_log2)) + r16;       // position inside the tile
     const bool zero_d0 = tq == 0;                                   // frame -1
     const bool zero_d5 = 4 * tq + 4 >= T;                           // frame T
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
@@ -1055,11 +1063,53 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     }
 
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + store: lane holds rows 4g..4g+3 of quad column r16 of its block
-    const bool stats = prm.stat_sum != nullptr;
-    float* red = pool;
-    if (stats) __syncthreads();
     const int pos = pos0 + col;
     const bool ok = pos < HW;
+    float* red = pool;
+    if constexpr (EPI != 2) {
+        // rows 16 i + r and frames f are scalar offsets of a buffer store; a lane outside the map (or, on the last row tile, a row
+        // beyond M) gets an offset past the descriptor's range: the store is dropped, no branch
+        constexpr unsigned OOB = 0xFFFFFFFFu;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(OUT, 0, prm.out_bytes, 0x00020000);
+        const unsigned lane_off = ok ? 4u * (unsigned)(n_img * prm.M * prm.S + 4 * tq * HW + pos + (m0 + 4 * g) * prm.S) : OOB;
+        const bool ragged = m0 + BM > prm.M;                  // (wave-uniform)
+        const int row_bytes = 4 * prm.S, frame_bytes = 4 * HW;
+        if (EPI == 1) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
+                const float s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
+                const float y[4] = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
+                unsigned voff = lane_off;
+                bool live = ok;
+                if (ragged) {
+                    live = ok && m0 + 16 * i + 4 * g + r < prm.M;
+                    voff = live ? lane_off : OOB;
+                }
+                const int soff = (16 * i + r) * row_bytes;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[f]), orsrc, (int)voff, soff + f * frame_bytes, 0);
+                if constexpr (EPI == 1) {
+                    float s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
+                    float s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
+                    // the 16 lanes of a DPP row share output row m: quad swaps, then the two mirrors
+#define ZSV_ROW16_SUM(v)                                                                                                         \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));                               \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));                               \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+                    ZSV_ROW16_SUM(s1)
+                    ZSV_ROW16_SUM(s2)
+#undef ZSV_ROW16_SUM
+                    if (r16 == 0) *reinterpret_cast<f32x2*>(&red[(wave * BM + 16 * i + 4 * g + r) * 2]) = f32x2{s1, s2};
+                }
+            }
+        }
+    } else {
+    const bool stats = prm.stat_sum != nullptr;
+    if (stats) __syncthreads();
     const int off0 = n_img * prm.M * prm.S + 4 * tq * HW + pos;        // frame 4*tq; the next three are HW further each
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1096,7 +1146,8 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
             }
         }
     }
-    if (stats) {
+    }
+    if (EPI == 1 || (EPI == 2 && prm.stat_sum != nullptr)) {
         __syncthreads();
         if (tid < BM && m0 + tid < prm.M) {
             const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
@@ -1277,14 +1328,19 @@ static int winot_launch(const WinoParams& p, const float* up, const float* in, f
     return launch_status();
 }
 
-template <int TM, bool PRE>
-static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+template <int TM, bool PRE, int EPI>
+static int winot4_launch_epi(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 260 + (PRE ? 256 : 0);               // as in the kernel
     constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_winot4_kernel<TM, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_winot4_kernel<TM, PRE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    hipLaunchKernelGGL((conv_winot4_kernel<TM, PRE>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    hipLaunchKernelGGL((conv_winot4_kernel<TM, PRE, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
+}
+template <int TM, bool PRE>
+static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    if (p.add != nullptr || p.bias != nullptr || p.relu || ZSV_KNOB(WINOT_GENERIC_EPILOGUE)) return winot4_launch_epi<TM, PRE, 2>(p, up, in, out, stream);
+    return p.stat_sum != nullptr ? winot4_launch_epi<TM, PRE, 1>(p, up, in, out, stream) : winot4_launch_epi<TM, PRE, 0>(p, up, in, out, stream);
 }
 
 // the temporal form: M rows from C reduction channels; G[m][c][kt] = w[m*sm + c*sc + (flip ? 2 - kt : kt)]
@@ -1304,6 +1360,8 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.P = d->N * p.S;
     p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
     p.PW = 256 / d->Ti;
+    p.pw_log2 = d->Ti == 4 ? 6 : d->Ti == 8 ? 5 : 4;
+    p.out_bytes = 4u * (unsigned)((long)d->N * M * p.S);
     p.segs = winot_segs(d);
     p.tiles_m = p.Mp / bm;
     p.tiles_n = d->N * p.segs;

@@ -55,7 +55,8 @@
     X(NO_PACK_TILED) \
     X(NO_T2_DENSE) \
     X(WINO_NO_VW) \
-    X(WINO_VW_MIN_WGS)
+    X(WINO_VW_MIN_WGS) \
+    X(WINOT_GENERIC_EPILOGUE)
 
 namespace zsv {
 enum KnobId {
