@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--pre", action="store_true",
                     help="forward / wgrad through the BatchNorm-folded entry points (zsv_conv3d_fwd_pre / _wgrad_pre: the kernels a "
                          "training step runs for the stride-1 temporal convolutions) where the geometry supports them")
+    ap.add_argument("--stats", action="store_true", help="forward with the BatchNorm partial statistics in the epilogue (the training forward) where supported")
+    ap.add_argument("--add", action="store_true", help="dgrad with the fused shortcut-gradient add where supported")
     ap.add_argument("--markers", action="store_true",
                     help="launch a one-element fill kernel in front of every (shape, kind) group: tools/kernel_breakdown.py splits a "
                          "rocprofv3 kernel trace of this run at those markers")
@@ -92,12 +94,22 @@ def main():
             "dgrad": lambda: lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), wsf.data_ptr(), nd, stream),
             "wgrad": lambda: lib.zsv_conv3d_wgrad(ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, stream),
         }
+        if args.stats:
+            tiles = lib.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr())
+            if tiles > 0:
+                st = torch.empty(2, cout, tiles, device=dev)
+                calls["fwd"] = lambda: lib.zsv_conv3d_fwd_stats(ctypes.byref(d), x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, st.data_ptr(), tiles, wsf.data_ptr(), nf, stream)
+        if args.add and lib.zsv_conv3d_dgrad_add_supported(ctypes.byref(d)):
+            addt = torch.randn_like(x)
+            calls["dgrad"] = lambda: lib.zsv_conv3d_dgrad_add(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), addt.data_ptr(), dx.data_ptr(), wsf.data_ptr(), nd, stream)
         if args.pre and lib.zsv_conv3d_pre_supported(ctypes.byref(d)):
             pitch = (cin + 15) // 16 * 16
             coef = torch.zeros(2, pitch, device=dev)
             coef[0, :cin] = 1.0 + 0.1 * torch.randn(cin, device=dev)
             coef[1, :cin] = 0.1 * torch.randn(cin, device=dev)
-            calls["fwd"] = lambda: lib.zsv_conv3d_fwd_pre(ctypes.byref(d), x.data_ptr(), coef.data_ptr(), pitch, wt.data_ptr(), y.data_ptr(), None, 0, wsf.data_ptr(), nf, stream)
+            tiles_p = lib.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr()) if args.stats else 0
+            st_p = torch.empty(2, cout, max(tiles_p, 1), device=dev)
+            calls["fwd"] = lambda: lib.zsv_conv3d_fwd_pre(ctypes.byref(d), x.data_ptr(), coef.data_ptr(), pitch, wt.data_ptr(), y.data_ptr(), st_p.data_ptr() if tiles_p > 0 else None, tiles_p, wsf.data_ptr(), nf, stream)
             calls["wgrad"] = lambda: lib.zsv_conv3d_wgrad_pre(ctypes.byref(d), x.data_ptr(), coef.data_ptr(), pitch, dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), nb, stream)
         for kind in args.kinds.split(","):
             fn = calls[kind]

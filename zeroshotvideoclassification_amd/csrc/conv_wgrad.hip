@@ -32,17 +32,6 @@ namespace zsv {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-struct Magic { unsigned mul, shift; };     // q = (umulhi(p, mul) + p) >> shift, exact for p < 2^31
-static Magic make_magic(unsigned d) {
-    Magic m;
-    unsigned s = 0;
-    while ((1ull << s) < d) ++s;
-    m.shift = s;
-    m.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);     // ceil(2^(32+s)/d) - 2^32
-    return m;
-}
-__device__ __forceinline__ unsigned mdiv(unsigned p, Magic m) { return (__umulhi(p, m.mul) + p) >> m.shift; }
-
 struct WgradParams {
     int M;                  // Cout
     int Cin, Cpad, nblk;    // channels, padded to 16, 16-channel blocks per tap

@@ -33,6 +33,7 @@ namespace zsv {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoParams {
     int M, Mp;              // output channels, padded to 64
@@ -40,6 +41,8 @@ struct WinoParams {
     int S, HW, W, H, T;     // voxels per clip / frame, row length, rows, frames
     int kT, R;              // temporal taps (1 or 3, pad kT/2), row taps R = 3*kT (a row tap = one (kt, kh))
     int P;                  // N * S
+    Magic m_S, m_HW, m_W, m_TH, m_H, m_tiles_m, m_ksplit;    // divisions of the F(4,3) kernel's prologue (conv_wino4_kernel)
+    int wv_log2;
     int Wv, Pv;             // virtual-width form (conv_wino4_kernel VW): rows padded to Wv = 8 / 16 / 32 / 64 voxels, Pv = N * T * H * Wv
     unsigned in_bytes, u_bytes;   // bytes of the input tensor / of the transformed-weight array
     int tiles_m, tiles_n;
@@ -401,7 +404,11 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 // exist (d0 of a row's first quad and d5 of its last are the zero padding).  7-wide rows run F(4,3) on 8 columns: 12 multiplies
 // per 7 outputs against 21 (1.75x fewer MFMAs than the direct kernel they used to take); 14-wide rows 24 per 14 against the
 // F(2,3) kernel's 28, with 16-byte image DMAs instead of 4-byte ones.
-template <int TM, int NCHUNKS, bool VW = false>
+// EPI: the epilogue, chosen at compile time (as conv_winot4_kernel): bit 0 = BatchNorm partial statistics, bit 1 = + add (the
+// identity-shortcut gradient of zsv_conv3d_dgrad_add), 4 = the run-time-flag form (bias / ReLU / residual of the inference engine).
+// EPI < 4 is branch-free: 16-byte buffer stores (and loads of `add`) with scalar row offsets, lanes outside the problem dropped by
+// the descriptor's range check.
+template <int TM, int NCHUNKS, bool VW = false, int EPI = 4>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, const float* __restrict__ Up,
                                                             const float* __restrict__ IN, float* __restrict__ OUT) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -420,9 +427,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lid = xcd_tile(gridDim.x, blockIdx.x);
-    const int split = lid % prm.ksplit, tile = lid / prm.ksplit;
-    const int m0 = (tile % prm.tiles_m) * BM;
-    const int n0 = (tile / prm.tiles_m) * BN;
+    const int tile = (int)mdiv((unsigned)lid, prm.m_ksplit), split = lid - tile * prm.ksplit;
+    const int ctile = (int)mdiv((unsigned)tile, prm.m_tiles_m);
+    const int m0 = (tile - ctile * prm.tiles_m) * BM;
+    const int n0 = ctile * BN;
     if (prm.ksplit > 1) OUT += (size_t)split * prm.slab_elems;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
@@ -431,21 +439,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     auto locate = [&](int p, int& n, int& sp, int& t, int& h, int& wv) -> bool {
         if constexpr (VW) {
             if (p < 0 || p >= prm.Pv) return false;
-            const int row = p / prm.Wv;
-            wv = p - row * prm.Wv;
-            n = row / (prm.T * prm.H);
+            const int row = p >> prm.wv_log2;
+            wv = p - (row << prm.wv_log2);
+            n = (int)mdiv((unsigned)row, prm.m_TH);
             const int rr = row - n * (prm.T * prm.H);
-            t = rr / prm.H;
+            t = (int)mdiv((unsigned)rr, prm.m_H);
             h = rr - t * prm.H;
             sp = rr * prm.W + wv;
             return true;
         } else {
             if (p < 0 || p >= prm.P) return false;
-            n = p / prm.S;
+            n = (int)mdiv((unsigned)p, prm.m_S);
             sp = p - n * prm.S;
-            t = sp / prm.HW;
+            t = (int)mdiv((unsigned)sp, prm.m_HW);
             const int r = sp - t * prm.HW;
-            h = r / prm.W;
+            h = (int)mdiv((unsigned)r, prm.m_W);
             wv = r - h * prm.W;
             return true;
         }
@@ -531,7 +539,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 
     const int g = lane >> 4, r16 = lane & 15;
     const int v_first = n0 + 64 * wave + 4 * r16;                  // first (virtual) voxel of this lane's quad
-    const int w_first = v_first % (VW ? prm.Wv : prm.W);
+    int n_clip = 0, sp_first = 0, w_first = 0;
+    bool quad_ok;
+    {
+        int t_, h_;
+        quad_ok = locate(v_first, n_clip, sp_first, t_, h_, w_first);
+    }
     const bool zero_d0 = w_first == 0, zero_d5 = w_first + 4 >= prm.W;
     const int nvalid = VW ? prm.W - w_first : 4;                    // VW: real voxels of the quad (1..4 at a row's end; W > Wv - 4)
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
@@ -611,15 +624,87 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     if ((W4ABL & 8) && prm.P > 0) return;
 
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + 16-byte stores: lane holds rows 4g..4g+3 of quad column r16
+    if constexpr (EPI < 4) {
+        constexpr bool STATS = (EPI & 1) != 0, ADD = (EPI & 2) != 0;
+        constexpr unsigned OOBS = 0xFFFFFFF0u;
+        float* red = pool;
+        if (STATS) __syncthreads();
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(OUT, 0, prm.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? prm.add : IN), 0, ADD ? prm.out_bytes : 0u, 0x00020000);
+        // byte offset of (row m0 + 4g, this quad); rows 16 i + r go into the scalar offset
+        const unsigned lane_off = quad_ok ? 4u * (unsigned)(n_clip * prm.M * prm.S + sp_first + (m0 + 4 * g) * prm.S) : OOBS;
+        const bool ragged = m0 + BM > prm.M;                  // (wave-uniform)
+        const int row_bytes = 4 * prm.S;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f32x4 addv[4];
+            if constexpr (ADD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned voff = (ragged && m0 + 16 * i + 4 * g + r >= prm.M) ? OOBS : lane_off;
+                    if (!VW || nvalid >= 4) {
+                        addv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (int)voff, (16 * i + r) * row_bytes, 0));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            addv[r][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, (int)(e < nvalid ? voff + 4u * e : OOBS), (16 * i + r) * row_bytes, 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
+                const float s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
+                f32x4 y = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
+                bool live = quad_ok;
+                unsigned voff = lane_off;
+                if (ragged) {
+                    live = quad_ok && m0 + 16 * i + 4 * g + r < prm.M;
+                    voff = live ? lane_off : OOBS;
+                }
+                if constexpr (STATS) {
+                    if constexpr (VW) {                        // only the real voxels of a row's last quad count
+                        y[1] = nvalid < 2 ? 0.f : y[1];
+                        y[2] = nvalid < 3 ? 0.f : y[2];
+                        y[3] = nvalid < 4 ? 0.f : y[3];
+                    }
+                    float s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
+                    float s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
+#define ZSV_ROW16_SUM(v)                                                                                                         \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));                               \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));                               \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+                    ZSV_ROW16_SUM(s1)
+                    ZSV_ROW16_SUM(s2)
+#undef ZSV_ROW16_SUM
+                    if (r16 == 0) *reinterpret_cast<f32x2*>(&red[(wave * BM + 16 * i + 4 * g + r) * 2]) = f32x2{s1, s2};
+                }
+                if constexpr (ADD) y += addv[r];
+                const int soff = (16 * i + r) * row_bytes;
+                if (!VW || nvalid >= 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), orsrc, (int)voff, soff, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), orsrc, (int)(e < nvalid ? voff + 4u * e : OOBS), soff, 0);
+                }
+            }
+        }
+        if constexpr (STATS) {
+            __syncthreads();
+            if (tid < BM && m0 + tid < prm.M) {               // the 4 waves' partials, in wave order
+                const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
+                const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
+                const int tn = n0 / BN;
+                prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + tn] = t1;
+                prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + tn] = t2;
+            }
+        }
+    } else {
     const bool stats = prm.stat_sum != nullptr;
     float* red = pool;                                   // [4 waves][BM][2] partial sums (the staging LDS is free now)
     if (stats) __syncthreads();
-    int n_clip = 0, sp_first = 0;
-    bool quad_ok;
-    {
-        int t_, h_, wv_;
-        quad_ok = locate(v_first, n_clip, sp_first, t_, h_, wv_);
-    }
     const int quad_off = n_clip * prm.M * prm.S + sp_first;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -676,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             prm.stat_sum[(size_t)(m0 + tid) * prm.tiles_n + tn] = t1;
             prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + tn] = t2;
         }
+    }
     }
 #endif
 }
@@ -1308,15 +1394,22 @@ static int wino_launch(const WinoParams& p, const float* up, const float* in, fl
     return launch_status();
 }
 
-template <int TM, int NCHUNKS, bool VW = false>
-static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+template <int TM, int NCHUNKS, bool VW, int EPI>
+static int wino4_launch_epi(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 272 + 64;                           // as in the kernel
     constexpr int LDS_BYTES = (TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) * 4;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_wino4_kernel<TM, NCHUNKS, VW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
     const long tiles = (long)p.tiles_m * p.tiles_n * p.ksplit;
-    hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS, VW>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
+    hipLaunchKernelGGL((conv_wino4_kernel<TM, NCHUNKS, VW, EPI>), dim3((unsigned)tiles), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
+}
+template <int TM, int NCHUNKS, bool VW = false>
+static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    if (p.bias != nullptr || p.relu || (p.add != nullptr && p.stat_sum != nullptr) || ZSV_KNOB(WINO_GENERIC_EPILOGUE))
+        return wino4_launch_epi<TM, NCHUNKS, VW, 4>(p, up, in, out, stream);
+    if (p.add != nullptr) return wino4_launch_epi<TM, NCHUNKS, VW, 2>(p, up, in, out, stream);
+    return p.stat_sum != nullptr ? wino4_launch_epi<TM, NCHUNKS, VW, 1>(p, up, in, out, stream) : wino4_launch_epi<TM, NCHUNKS, VW, 0>(p, up, in, out, stream);
 }
 
 template <int TM, bool PRE>
@@ -1404,7 +1497,13 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     p.P = d->N * p.S;
     p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
     p.tiles_m = p.Mp / bm;
+    p.out_bytes = 4u * (unsigned)((long)d->N * M * p.S);
     p.Wv = wino_vw_width(d);
+    p.wv_log2 = 0;
+    while ((1 << p.wv_log2) < p.Wv) ++p.wv_log2;
+    p.m_S = make_magic((unsigned)p.S); p.m_HW = make_magic((unsigned)p.HW); p.m_W = make_magic((unsigned)p.W);
+    p.m_TH = make_magic((unsigned)(p.T * p.H)); p.m_H = make_magic((unsigned)p.H);
+    p.m_tiles_m = make_magic((unsigned)p.tiles_m); p.m_ksplit = make_magic((unsigned)ks);
     p.Pv = p.Wv ? d->N * d->Ti * d->Hi * p.Wv : p.P;
     p.tiles_n = (p.Pv + 255) / 256;
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;

@@ -56,7 +56,8 @@
     X(NO_T2_DENSE) \
     X(WINO_NO_VW) \
     X(WINO_VW_MIN_WGS) \
-    X(WINOT_GENERIC_EPILOGUE)
+    X(WINOT_GENERIC_EPILOGUE) \
+    X(WINO_GENERIC_EPILOGUE)
 
 namespace zsv {
 enum KnobId {

@@ -30,6 +30,18 @@ __device__ __forceinline__ T block_sum_256(T v, T* scratch) {
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+// unsigned division by a run-time constant without the ~25-instruction divide: q = (umulhi(p, mul) + p) >> shift, exact for p < 2^31
+struct Magic { unsigned mul, shift; };
+static inline Magic make_magic(unsigned d) {
+    Magic m;
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    m.shift = s;
+    m.mul = (unsigned)((((1ull << s) - d) << 32) / d + 1);     // ceil(2^(32+s)/d) - 2^32
+    return m;
+}
+__device__ __forceinline__ unsigned mdiv(unsigned p, Magic m) { return (__umulhi(p, m.mul) + p) >> m.shift; }
+
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 5; }
 
 }  // namespace zsv
