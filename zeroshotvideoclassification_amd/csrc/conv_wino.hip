@@ -683,7 +683,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
                 if constexpr (ADD) y += addv[r];
                 const int soff = (16 * i + r) * row_bytes;
                 if (!VW || nvalid >= 4) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), orsrc, (int)voff, soff, 0);
+                    // The row offset goes into the VECTOR offset here (one add), not into the scalar offset as for the 4-byte
+                    // stores: a 16-byte buffer store with an SGPR soffset followed at once by a VALU write of its data registers
+                    // stored the NEW value of the last dword now and then on gfx950 (elements w % 4 == 3 of single rows, a few
+                    // hundred per 10^7); the compiler's hazard table (1 wait state for > 64-bit store data) only covers the
+                    // immediate-soffset form, which this is.
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), orsrc, (int)(live ? voff + (unsigned)soff : OOBS), 0, 0);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 3; ++e)
