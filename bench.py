@@ -54,12 +54,12 @@ S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, 
 # the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step;
 # `mfma_saving`: direct-convolution MACs / MACs the Winograd F(4,3)-along-W form executes (12 -> 6 per 4 outputs)
 DOMINANT = {
-    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino4_kernel<3, 12>", mfma_saving=2.0,
-                        pmc_key="conv_wino4_kernel<3, 12>",
+    "r2plus1d_18": dict(geometry=S1_GEOMETRY, launches=4, symbol="zsv::conv_wino4_kernel<3, 12, false, 1>", mfma_saving=2.0,
+                        pmc_key="conv_wino4_kernel<3, 12, false, 1>", pmc_key_old="conv_wino4_kernel<3, 12>",
                         what="Conv3d(64,144,(1,3,3)) forward @16x56x56 (resnet.py:40-45, layer1 spatial half of Conv2Plus1D)"),
     # network.py:105 conv2 = Conv3d(64,128,3x3x3, pad 1) after pool1 (1,2,2): 22.2 GFLOP/clip, 29 % of C3D's forward FLOPs
     "c3d": dict(geometry=dict(Cin=64, Cout=128, kT=3, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56), launches=1,
-                symbol="zsv::conv_wino4_kernel<4, 0>", mfma_saving=2.0, pmc_key=None,
+                symbol="zsv::conv_wino4_kernel<4, 0, false, 4>", mfma_saving=2.0, pmc_key=None,
                 what="Conv3d(64,128,3x3x3) forward @16x56x56 (network.py:105 conv2)"),
 }
 BASELINE_CONFIG = {"r2plus1d_18": "BASELINE.json configs[1]; configs[2] when n_gpus > 1", "c3d": "BASELINE.json configs[3]"}
@@ -237,13 +237,16 @@ def usable_cores() -> int:
     return max(1, min(n, int(os.environ.get("ZSV_CPU_THREADS", "64"))))
 
 
-def _profile_entry(files, key):
+def _profile_entry(files, keys):
     for name in files:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][key], name
+                kernels = json.load(f)["kernels"]
         except Exception:
             continue
+        for key in keys:
+            if key and key in kernels:
+                return kernels[key], name
     return None, None
 
 
@@ -253,7 +256,7 @@ def pmc_traffic(dom, n_clips: int):
     profiled one or no pass is committed for this kernel."""
     if not dom.get("pmc_key") or n_clips != CLIPS_PER_GPU:
         return None
-    k, _ = _profile_entry(PMC_TRAFFIC_FILES, dom["pmc_key"])
+    k, _ = _profile_entry(PMC_TRAFFIC_FILES, (dom["pmc_key"], dom.get("pmc_key_old")))
     return round(k["hbm_bytes"]) if k and "hbm_bytes" in k else None
 
 
@@ -262,7 +265,7 @@ def pmc_busy(dom):
     ``--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE`` pass."""
     if not dom.get("pmc_key"):
         return None, None, None
-    k, name = _profile_entry(PMC_BUSY_FILES, dom["pmc_key"])
+    k, name = _profile_entry(PMC_BUSY_FILES, (dom["pmc_key"], dom.get("pmc_key_old")))
     if not k:
         return None, None, None
     return k.get("mfma_pipe_utilisation"), k.get("clock_GHz"), name
@@ -516,6 +519,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    # --input u8: the resident-input rate of the SAME process and device right after (devices of the pool differ by a few percent)
+    resident_ref = None
+    if feeder is not None:
+        xr = synthetic.synthetic_clips(args.batch, FRAMES, SIZE, rank=rank).to(dev)
+        for _ in range(2):
+            train.train_step(model, optimizer, criterion, xr, z, sync)
+        barrier()
+        tr = time.perf_counter()
+        for _ in range(args.steps):
+            train.train_step(model, optimizer, criterion, xr, z, sync)
+        barrier()
+        resident_ref = 1e3 * (time.perf_counter() - tr) / args.steps
+        del xr
+
     # host time to queue ONE step on an idle queue (no back-pressure from a full HIP queue): after the timed region
     enqueue = []
     for _ in range(3):
@@ -586,6 +603,9 @@ def main():
         }
         if feeder is not None:
             out["config"]["pcie_bytes_per_step"] = int(feeder.bytes_per_step)
+            out["resident_input_same_process"] = {"ms_per_step": round(resident_ref, 3),
+                                                  "value": round(world * args.batch / (resident_ref * 1e-3), 3), "unit": "clips/s",
+                                                  "u8_over_resident": round(resident_ref / ms_per_step, 4)}
             out["config"]["input_pipeline"] = ("pinned uint8 (N,T,H,W,3) -> hipMemcpyAsync on a copy stream, two slots -> "
                                                "zsv_clip_transform (auxiliary/transforms.py:41-56) -> model")
         if sync is not None:
