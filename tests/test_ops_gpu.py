@@ -1290,71 +1290,3 @@ def test_conv3d_winograd_virtual_width(case, monkeypatch):
     close(y, y2.double(), rtol=1e-5, what="virtual width vs previous kernel, forward")
     close(dx, dx2.double(), rtol=1e-5, what="virtual width vs previous kernel, dgrad")
     assert not torch.equal(y, y2) and not torch.equal(dx, dx2), "the two paths should not be the same kernel"
-
-
-@pytest.mark.parametrize("n,cin,cout,thw,pre", [(3, 144, 64, (16, 24, 28), True), (5, 64, 144, (16, 20, 20), False), (4, 230, 128, (8, 14, 18), True),
-                                                (6, 40, 100, (4, 10, 14), False), (2, 45, 64, (16, 56, 56), False)],
-                         ids=["t1_like_folded_bn", "t1_dgrad_like_144_rows", "t3_like_t8", "t4_ragged_rows_partial_segments", "t0_like_full_width"])
-def test_temporal_winograd_persistent_workgroups(n, cin, cout, thw, pre, monkeypatch):
-    """conv_winot4p_kernel: resident workgroups pull the tiles of the temporal F(4,3) convolution from per-XCD queues and run the
-    chunk stream across tile boundaries.  Same arithmetic in the same order as the one-tile-per-workgroup kernel: forward (plain /
-    BatchNorm-folded, with and without the statistics epilogue) and input gradient are BIT-identical (ZSV_WINOT_NO_PERSIST=1), and
-    right against torch CPU fp64."""
-    import ctypes
-    from zeroshotvideoclassification_amd import _lib
-    t, h, w = thw
-    g = torch.Generator().manual_seed(cin * 3 + cout)
-    x = torch.randn(n, cin, t, h, w, generator=g)
-    wt = torch.randn(cout, cin, 3, 1, 1, generator=g) / np.sqrt(3 * cin)
-    dy = torch.randn(n, cout, t, h, w, generator=g)
-    scale, shift = 1.0 + 0.2 * torch.randn(cin, generator=g), 0.3 * torch.randn(cin, generator=g)
-    lib = _lib.load()
-    d = ops.conv_desc(x.shape, wt.shape, 1, (1, 0, 0))
-    xd, wd, dyd = x.to(DEV), wt.to(DEV), dy.to(DEV)
-    pitch = (cin + 15) // 16 * 16
-    coef = torch.zeros(2, pitch)
-    coef[0, :cin], coef[1, :cin] = scale, shift
-    coefd = coef.to(DEV)
-
-    def run():
-        lib2 = _lib.load()
-        nf = lib2.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d))
-        nd = lib2.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
-        ws = torch.empty(max(int(nf), int(nd), 16), dtype=torch.uint8, device=DEV)
-        out = {}
-        for with_stats in (False, True):
-            y = torch.full((n, cout, t, h, w), float("nan"), device=DEV)
-            tiles = lib2.zsv_conv3d_fwd_stat_tiles(ctypes.byref(d), y.data_ptr()) if with_stats else 0
-            st = torch.full((2, cout, max(tiles, 1)), float("nan"), device=DEV)
-            sp = st.data_ptr() if tiles > 0 else None
-            if pre:
-                assert lib2.zsv_conv3d_pre_supported(ctypes.byref(d))
-                _lib.check(lib2.zsv_conv3d_fwd_pre(ctypes.byref(d), xd.data_ptr(), coefd.data_ptr(), pitch, wd.data_ptr(), y.data_ptr(), sp, tiles,
-                                                   ws.data_ptr(), nf, None), "fwd_pre")
-            else:
-                _lib.check(lib2.zsv_conv3d_fwd_stats(ctypes.byref(d), xd.data_ptr(), wd.data_ptr(), None, y.data_ptr(), 0, sp, tiles, ws.data_ptr(), nf, None), "fwd")
-            torch.cuda.synchronize()
-            out["y_stats" if with_stats else "y"] = y
-            if with_stats:
-                assert tiles > 0
-                out["stats"] = st
-        dx = torch.full((n, cin, t, h, w), float("nan"), device=DEV)
-        _lib.check(lib2.zsv_conv3d_dgrad(ctypes.byref(d), dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), ws.data_ptr(), nd, None), "dgrad")
-        torch.cuda.synchronize()
-        out["dx"] = dx
-        return out
-
-    monkeypatch.setenv("ZSV_WINOT_PERSIST_MIN_TILES", "2")
-    a = run()
-    a2 = run()
-    monkeypatch.setenv("ZSV_WINOT_NO_PERSIST", "1")
-    b = run()
-    for k in a:
-        assert torch.isfinite(a[k]).all(), k
-        assert torch.equal(a[k], a2[k]), f"{k}: run to run"
-        assert torch.equal(a[k], b[k]), f"{k}: persistent vs one tile per workgroup"
-    xin = torch.relu(x.double() * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)) if pre else x.double()
-    ref = F.conv3d(xin, wt.double(), padding=(1, 0, 0))
-    close(a["y"], ref, what="forward")
-    close(a["stats"][0].double().sum(1), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, what="sum y")
-    close(a["dx"], torch.nn.grad.conv3d_input(x.shape, wt.double(), dy.double(), padding=(1, 0, 0)), what="dgrad")

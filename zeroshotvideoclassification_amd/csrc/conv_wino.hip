@@ -367,10 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 // With 64 rows the two stages of U panels do not fit twice per CU (2 x 82 KB), so there the U panel is single-buffered:
 // a second barrier per chunk separates the fragment reads of a chunk from the DMAs of the next one.
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
-                                                         int C, int nblk, int R, long sm, long sc, int flip, long total,
-                                                         unsigned* __restrict__ counters = nullptr) {
-    // (the tile queues of the persistent temporal kernel that follows on the same stream: zeroed here, no launch of their own)
-    if (counters != nullptr && blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0u;
+                                                         int C, int nblk, int R, long sm, long sc, int flip, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c16 = (int)(i % 16);
         long r = i / 16;
@@ -1253,266 +1250,6 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
 #endif
 }
 
-// ================================================================================================
-// The temporal F(4,3) kernel with PERSISTENT workgroups (the training forward and the input gradients: EPI 0 / 1).
-// A tile of these layers is only 3 - 18 K chunks long (K = 45 .. 288 channels), so in conv_winot4_kernel every workgroup starts
-// cold: its first chunk's DMAs cross the whole memory latency before the first MFMA, then comes the address arithmetic of
-// the prologue, at the end the stores -- on the layer1 input gradient (4 chunks, 288 MFMAs per wave) the matrix pipe was busy
-// 43 - 50 % of the time (profiles/r03_s1_mfma_busy.json).  Here 512 workgroups (two per CU) stay resident and pull tiles from
-// eight queues (one per XCD: atomic counters over that XCD's contiguous tile range, zeroed by the weight-transform launch in
-// front): the chunk stream runs on across tile boundaries -- while the last chunk of a tile is computed the first chunk of the
-// next tile is already on its way into the other LDS stage, and the next tile's address arithmetic sits between MFMA bursts.
-// Same arithmetic in the same order as conv_winot4_kernel: bit-identical results (tested).  Every workgroup leaves when its
-// queue is empty; there is no dependency between workgroups.
-template <int TM, bool PRE, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_winot4p_kernel(WinoParams prm, const float* __restrict__ Up,
-                                                              const float* __restrict__ IN, float* __restrict__ OUT,
-                                                              unsigned* __restrict__ counters, int total_tiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(EPI == 0 || EPI == 1, "persistent form: plain or statistics epilogue");
-    constexpr int BM = 16 * TM, BK = 16, NP = 6;
-    constexpr bool USINGLE = TM >= 4;
-    constexpr int LDB = 260;
-    constexpr int A_FLOATS = NP * BM * BK, B_FLOATS = BK * LDB;
-    constexpr int IMG = B_FLOATS + (PRE ? 256 : 0);
-    constexpr int STAGE = A_FLOATS + IMG;
-    constexpr int POOL = USINGLE ? A_FLOATS + 2 * IMG : 2 * STAGE;
-    constexpr unsigned OOB16 = 0xFFFFFFF0u, OOB = 0xFFFFFFFFu;
-    extern __shared__ __attribute__((aligned(16))) float pool[];
-    float* red = pool + POOL;                            // [4 waves][BM][2] statistics partials (EPI 1), then the queue slot
-    int* next_slot = reinterpret_cast<int*>(pool + POOL + 4 * BM * 2);
-    auto u_of = [&](int buf) -> float* { return pool + (USINGLE ? 0 : buf * STAGE); };
-    auto img_of = [&](int buf) -> float* { return pool + (USINGLE ? A_FLOATS + buf * IMG : buf * STAGE + A_FLOATS); };
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = prm.T, PW = prm.PW, HW = prm.HW;
-    const int pq_log2 = prm.pw_log2 - 2;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(IN), 0, prm.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(OUT, 0, prm.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pre_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? prm.pre_coef : IN), 0, PRE ? 8u * (unsigned)prm.pre_pitch : 0u, 0x00020000);
-    const int ch_bytes = 4 * prm.S;
-
-    // this XCD's queue: the contiguous tile range xcd_tile() would give it
-    const int xcd = blockIdx.x & 7;
-    const int q8 = total_tiles >> 3, r8 = total_tiles & 7;
-    const int q_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int q_cnt = q8 + (xcd < r8 ? 1 : 0);
-    auto grab = [&]() -> int {                           // thread 0 only; -1 = queue empty
-        const unsigned k = atomicAdd(&counters[xcd], 1u);
-        return k < (unsigned)q_cnt ? q_lo + (int)k : -1;
-    };
-
-    // ---- lane constants that do not depend on the tile ------------------------------------------------------------------
-    const int pf = lane >> pq_log2, pl = 4 * (lane - (pf << pq_log2));     // frame and first position (inside the tile) of this lane's piece
-    constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
-    const float* a_lane[APASS];
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-        const int q = (3 - wave) + 4 * j, qq = q < NPIECES ? q : 0, pt = qq / TM, ib = qq % TM, row = lane >> 2;
-        const int sw = ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 4;
-        a_lane[j] = Up + ((size_t)pt * prm.Mp + 16 * ib + row) * 16 + sw;       // (+ 16 * m0 per tile)
-    }
-    const size_t a_chunk_stride = (size_t)NP * BK * prm.Mp;
-    const int nchunks = prm.nblk;
-    const int g = lane >> 4, r16 = lane & 15;
-    const int groups_log2 = prm.pw_log2 - 4;
-    const int tq = wave >> groups_log2;
-    const int col = 16 * (wave - (tq << groups_log2)) + r16;
-    const bool zero_d0 = tq == 0, zero_d5 = 4 * tq + 4 >= T;
-    const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
-    const int row_bytes = 4 * prm.S, frame_bytes = 4 * HW;
-
-    // ---- per-tile state: where the tile is (scalars) and this lane's piece of its image ------------------------------------
-    struct TileAt { int m0, ct, n_img, pos0; unsigned piece_off; };
-    auto locate = [&](int tile) -> TileAt {
-        TileAt t;
-        t.ct = (int)mdiv((unsigned)tile, prm.m_tiles_m);
-        t.m0 = (tile - t.ct * prm.tiles_m) * BM;
-        t.n_img = (int)mdiv((unsigned)t.ct, prm.m_ksplit);                    // (m_ksplit holds the magic of `segs` in the temporal form)
-        t.pos0 = (t.ct - t.n_img * prm.segs) * PW;
-        const int pp = t.pos0 + pl;
-        t.piece_off = pp < HW ? (unsigned)(4 * (t.n_img * prm.C * prm.S + pf * HW + pp)) : OOB16;
-        return t;
-    };
-    auto issue = [&](const TileAt& t, int chunk, int buf) {
-        float* as = u_of(buf);
-        float* bs = img_of(buf);
-        const int ci0 = chunk * 16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 4 * wave + j, ci = ci0 + k;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB), 16, (int)(ci < prm.C ? t.piece_off : OOB16),
-                                                     ci < prm.C ? ci * ch_bytes : 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            const int q = (3 - wave) + 4 * j;
-            if (q < NPIECES)
-                __builtin_amdgcn_global_load_lds(a_lane[j] + (size_t)chunk * a_chunk_stride + 16 * t.m0, (lds_ptr_t)(as + 256 * q), 16, 0, 0);
-        }
-        if constexpr (PRE) {
-            if (wave == 0) {
-                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : OOB16;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(bs + B_FLOATS), 16, (int)off, 0, 0, 0);
-            }
-        }
-    };
-
-    // ---- first tile ------------------------------------------------------------------------------------------------------------
-    if (tid == 0) *next_slot = grab();
-    __syncthreads();
-    int tile = __builtin_amdgcn_readfirstlane(*next_slot);
-    if (tile < 0) return;
-    TileAt cur = locate(tile);
-    issue(cur, 0, 0);
-    int stage = 0;
-    f32x4 acc[NP][TM];
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();                                   // (vmcnt(0) before the barrier: chunk 0 of the first tile has landed; every thread has read the slot)
-
-    for (;;) {
-        int grabbed = -1;
-        if (tid == 0) grabbed = grab();                 // the tile after this one: the atomic returns while chunk 0 is computed
-        TileAt nxt = cur;
-        int next_tile = -1;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const bool last = ch + 1 == nchunks;
-            auto issue_next = [&]() {                   // the chunk that follows in the stream: of this tile, or chunk 0 of the next one
-                if (!last) {
-                    issue(cur, ch + 1, stage ^ 1);
-                } else {
-                    next_tile = __builtin_amdgcn_readfirstlane(*next_slot);        // (published before the barrier that ended chunk 0; nchunks >= 2)
-                    if (next_tile >= 0) {
-                        nxt = locate(next_tile);
-                        issue(nxt, 0, stage ^ 1);
-                    }
-                }
-            };
-            if (!USINGLE) issue_next();
-            const float* as = u_of(stage);
-            const float* bs = img_of(stage);
-            f32x4 a4[NP][TM];
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a4[p][i] = *reinterpret_cast<const f32x4*>(as + (p * TM + i) * 256 + a_frag);
-            float psc[PRE ? 4 : 1], psh[PRE ? 4 : 1];
-            if constexpr (PRE) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    psc[s] = bs[B_FLOATS + 4 * g + s];
-                    psh[s] = bs[B_FLOATS + 16 + 4 * g + s];
-                }
-            }
-            float raw[2][NP];
-            auto fetch = [&](int s, int slot) {
-                const float* row = bs + (4 * g + s) * LDB;
-                const int f0 = 4 * tq - 1;
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    const int f = min(max(f0 + i, 0), T - 1);
-                    raw[slot][i] = row[f * PW + col];
-                }
-            };
-            fetch(0, 0);
-            if (USINGLE) {
-                __syncthreads();
-                issue_next();
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int sl = s & 1;
-                float d[NP];
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    d[i] = raw[sl][i];
-                    if constexpr (PRE) d[i] = fmaxf(__fmaf_rn(d[i], psc[s], psh[s]), 0.f);
-                }
-                const float d0 = zero_d0 ? 0.f : d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = zero_d5 ? 0.f : d[5];
-                float v[NP];
-                const float t12 = d1 + d2, t34 = d3 + d4, u12 = d1 - d2, u43 = d4 - d3, u42 = d4 - d2, u31 = d3 - d1;
-                v[0] = __fmaf_rn(4.f, d0, __fmaf_rn(-5.f, d2, d4));
-                v[1] = __fmaf_rn(-4.f, t12, t34);
-                v[2] = __fmaf_rn(4.f, u12, u43);
-                v[3] = __fmaf_rn(2.f, u31, u42);
-                v[4] = __fmaf_rn(-2.f, u31, u42);
-                v[5] = __fmaf_rn(4.f, d1, __fmaf_rn(-5.f, d3, d5));
-                if (s < 3) fetch(s + 1, sl ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (ch == 0 && tid == 0) *next_slot = grabbed;     // (the barrier below publishes it)
-            __syncthreads();                           // (vmcnt(0) lgkmcnt(0) + barrier: the next chunk has landed)
-            stage ^= 1;
-        }
-
-        // ---- epilogue of `cur` (conv_winot4_kernel's EPI 0 / 1 form); the next tile's first chunk is in flight ----------
-        {
-            const int pos = cur.pos0 + col;
-            const bool ok = pos < HW;
-            const unsigned lane_off = ok ? 4u * (unsigned)(cur.n_img * prm.M * prm.S + 4 * tq * HW + pos + (cur.m0 + 4 * g) * prm.S) : OOB;
-            const bool ragged = cur.m0 + BM > prm.M;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
-                    const float s12 = M1 + M2, d12 = M1 - M2, s34 = M3 + M4, d34 = M3 - M4;
-                    const float y[4] = {(M0 + s12) + s34, __fmaf_rn(2.f, d34, d12), __fmaf_rn(4.f, s34, s12), __fmaf_rn(8.f, d34, d12) + M5};
-                    unsigned voff = lane_off;
-                    bool live = ok;
-                    if (ragged) {
-                        live = ok && cur.m0 + 16 * i + 4 * g + r < prm.M;
-                        voff = live ? lane_off : OOB;
-                    }
-                    const int soff = (16 * i + r) * row_bytes;
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[f]), orsrc, (int)voff, soff + f * frame_bytes, 0);
-                    if constexpr (EPI == 1) {
-                        float s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
-                        float s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
-#define ZSV_ROW16_SUM(v)                                                                                                         \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));                               \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));                               \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));                              \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
-                        ZSV_ROW16_SUM(s1)
-                        ZSV_ROW16_SUM(s2)
-#undef ZSV_ROW16_SUM
-                        if (r16 == 0) *reinterpret_cast<f32x2*>(&red[(wave * BM + 16 * i + 4 * g + r) * 2]) = f32x2{s1, s2};
-                    }
-                    acc[0][i][r] = 0.f; acc[1][i][r] = 0.f; acc[2][i][r] = 0.f; acc[3][i][r] = 0.f; acc[4][i][r] = 0.f; acc[5][i][r] = 0.f;
-                }
-            }
-            if constexpr (EPI == 1) {
-                // (LDS-only barrier: the next tile's DMAs stay in flight; `red` is rewritten only after the chunk barriers of the next tile)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (tid < BM && cur.m0 + tid < prm.M) {
-                    const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
-                    const float t2 = (red[tid * 2 + 1] + red[(BM + tid) * 2 + 1]) + (red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1]);
-                    prm.stat_sum[(size_t)(cur.m0 + tid) * prm.tiles_n + cur.ct] = t1;
-                    prm.stat_sq[(size_t)(cur.m0 + tid) * prm.tiles_n + cur.ct] = t2;
-                }
-            }
-        }
-        if (next_tile < 0) break;
-        cur = nxt;
-    }
-#endif
-}
-
 // ---- host side -----------------------------------------------------------------------------------
 static size_t wino_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -1636,7 +1373,7 @@ static int wino_tm_for(const zsv_conv_desc* d, int M) {
 }
 static size_t wino_bytes(const zsv_conv_desc* d, int M, int C) {
     const int bm = 16 * wino_tm_for(d, M), Mp = (M + bm - 1) / bm * bm, nblk = (C + 15) / 16;
-    if (winot_shape(d)) return wino_align((size_t)nblk * 6 * 16 * Mp * sizeof(float)) + 256;      // (no row taps; 6 points: the F(4,3) form, the F(2,3) form uses 4; + the tile queues)
+    if (winot_shape(d)) return wino_align((size_t)nblk * 6 * 16 * Mp * sizeof(float));            // (no row taps; 6 points: the F(4,3) form, the F(2,3) form uses 4)
     const int points = wino_f43(d) ? 6 : 4;
     return wino_align((size_t)nblk * 3 * d->kT * points * 16 * Mp * sizeof(float));
 }
@@ -1698,29 +1435,9 @@ static int winot4_launch_epi(const WinoParams& p, const float* up, const float* 
     hipLaunchKernelGGL((conv_winot4_kernel<TM, PRE, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), LDS_BYTES, stream, p, up, in, out);
     return launch_status();
 }
-// persistent form (conv_winot4p_kernel): 512 resident workgroups pull the tiles from per-XCD queues
-template <int TM, bool PRE, int EPI>
-static int winot4p_launch(const WinoParams& p, const float* up, const float* in, float* out, unsigned* counters, hipStream_t stream) {
-    constexpr int A_FLOATS = 6 * 16 * TM * 16, IMG = 16 * 260 + (PRE ? 256 : 0);
-    constexpr int LDS_BYTES = ((TM >= 4 ? A_FLOATS + 2 * IMG : 2 * (A_FLOATS + IMG)) + 4 * 16 * TM * 2 + 4) * 4;     // stages + statistics partials + queue slot
-    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_winot4p_kernel<TM, PRE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    const int total = p.tiles_m * p.tiles_n;
-    const int grid = total < 512 ? total : 512;
-    hipLaunchKernelGGL((conv_winot4p_kernel<TM, PRE, EPI>), dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, p, up, in, out, counters, total);
-    return launch_status();
-}
-static bool winot4_persistent(const WinoParams& p) {
-    const char* e = ZSV_KNOB(WINOT_PERSIST_MIN_TILES);
-    const long min_tiles = e ? atol(e) : 1024;             // at least two tiles per resident workgroup (tests lower it)
-    return p.add == nullptr && p.bias == nullptr && !p.relu && p.nblk >= 2 && (long)p.tiles_m * p.tiles_n >= min_tiles &&
-           !ZSV_KNOB(WINOT_GENERIC_EPILOGUE) && !ZSV_KNOB(WINOT_NO_PERSIST);
-}
 template <int TM, bool PRE>
-static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, unsigned* counters, hipStream_t stream) {
+static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
     if (p.add != nullptr || p.bias != nullptr || p.relu || ZSV_KNOB(WINOT_GENERIC_EPILOGUE)) return winot4_launch_epi<TM, PRE, 2>(p, up, in, out, stream);
-    if (winot4_persistent(p))
-        return p.stat_sum != nullptr ? winot4p_launch<TM, PRE, 1>(p, up, in, out, counters, stream) : winot4p_launch<TM, PRE, 0>(p, up, in, out, counters, stream);
     return p.stat_sum != nullptr ? winot4_launch_epi<TM, PRE, 1>(p, up, in, out, stream) : winot4_launch_epi<TM, PRE, 0>(p, up, in, out, stream);
 }
 
@@ -1752,19 +1469,14 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     float* up = (float*)workspace;
     const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
     const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
-    unsigned* counters = (unsigned*)((char*)workspace + wino_bytes(d, M, C) - 256);      // the persistent kernel's tile queues
-    p.m_tiles_m = make_magic((unsigned)p.tiles_m);
-    p.m_ksplit = make_magic((unsigned)p.segs);                    // (the temporal kernels divide by `segs`, not by K parts)
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    if (f43)
-        hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip, total, counters);
-    else
-        hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip, total);
+    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip,
+                       total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     if (f43) {
-        if (pre_coef) return tm == 3 ? winot4_launch<3, true>(p, up, in, out, counters, stream) : winot4_launch<4, true>(p, up, in, out, counters, stream);
-        return tm == 3 ? winot4_launch<3, false>(p, up, in, out, counters, stream) : winot4_launch<4, false>(p, up, in, out, counters, stream);
+        if (pre_coef) return tm == 3 ? winot4_launch<3, true>(p, up, in, out, stream) : winot4_launch<4, true>(p, up, in, out, stream);
+        return tm == 3 ? winot4_launch<3, false>(p, up, in, out, stream) : winot4_launch<4, false>(p, up, in, out, stream);
     }
     if (pre_coef) return tm == 3 ? winot_launch<3, true>(p, up, in, out, stream) : winot_launch<4, true>(p, up, in, out, stream);
     return tm == 3 ? winot_launch<3, false>(p, up, in, out, stream) : winot_launch<4, false>(p, up, in, out, stream);
@@ -1811,10 +1523,8 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     const long total = (long)p.nblk * p.R * (f43 ? 6 : 4) * 16 * p.Mp;
     long pb = (total + 255) / 256;
     if (pb > 4096) pb = 4096;
-    if (f43)
-        hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, p.R, sm, sc, flip, total, (unsigned*)nullptr);
-    else
-        hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, p.R, sm, sc, flip, total);
+    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C,
+                       p.nblk, p.R, sm, sc, flip, total);
     if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
     const bool x4 = d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_X4) == nullptr;
     int st;

@@ -57,9 +57,7 @@
     X(WINO_NO_VW) \
     X(WINO_VW_MIN_WGS) \
     X(WINOT_GENERIC_EPILOGUE) \
-    X(WINO_GENERIC_EPILOGUE) \
-    X(WINOT_NO_PERSIST) \
-    X(WINOT_PERSIST_MIN_TILES)
+    X(WINO_GENERIC_EPILOGUE)
 
 namespace zsv {
 enum KnobId {
