@@ -660,3 +660,33 @@ def test_shared_weights_in_one_graph_with_the_wgrad_side_stream(monkeypatch):
         for k in ref:
             assert torch.equal(got[k], ref[k]), k
         assert got_hook == ref_hook
+
+
+def test_forward_hooks_see_the_reference_tensors():
+    """A forward hook on the mid BatchNorm3d / ReLU of a Conv2Plus1D (resnet.py:46-52) must receive the normalised / activated
+    tensor as with the reference's modules: hooked triples run the separate passes instead of the fold (which never materialises
+    it).  The model output does not change (the fold is bit-identical)."""
+    g, model, weights = build("r2plus1d_small")
+    x, _ = case_inputs(g)
+    xd = x.to(DEV)
+    model.train()
+    model.load_state_dict(weights)
+    with torch.no_grad():
+        ref = train.embed(model, xd).clone()
+    pair = model.model.layer1[0].conv1[0]                    # Conv2Plus1D: [spatial conv, BatchNorm3d, ReLU, temporal conv]
+    seen = {}
+    h1 = pair[1].register_forward_hook(lambda m, i, o: seen.__setitem__("bn", o))
+    h2 = pair[2].register_forward_hook(lambda m, i, o: seen.__setitem__("relu", o))
+    try:
+        model.load_state_dict(weights)
+        with torch.no_grad():
+            out = train.embed(model, xd)
+    finally:
+        h1.remove()
+        h2.remove()
+    assert torch.equal(out, ref)
+    bn, act = seen["bn"], seen["relu"]
+    assert torch.is_tensor(bn) and torch.is_tensor(act) and bn.shape == act.shape and bn.dim() == 5 and bn.shape[1] == pair[1].num_features
+    assert torch.equal(act, torch.relu(bn))
+    m = bn.mean(dim=(0, 2, 3, 4))
+    assert (m - pair[1].bias.detach()).abs().max().item() < 1e-4     # normalised: per-channel mean = beta

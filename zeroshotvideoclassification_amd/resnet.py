@@ -38,6 +38,12 @@ def _call(m: nn.Module, x: Tensor, want_stats: bool):
     return m(x), None
 
 
+def _has_hooks(*mods: nn.Module) -> bool:
+    """A forward (pre-)hook on one of the modules of a `BatchNorm -> ReLU -> conv` triple must see what the reference's module
+    would hand it (the normalised tensor, the activated tensor): such a triple takes the separate passes, not the fold."""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
+
 def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
     """Run conv / BN / ReLU children as fused kernel sequences: a convolution followed by a
     training-mode BatchNorm hands over its epilogue statistics (no separate pass over the
@@ -52,7 +58,7 @@ def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
             relu = isinstance(nxt, nn.ReLU)
             after = mods[i + 2] if (relu and i + 2 < n) else None
             if relu and m.training and m.momentum is not None and type(after) is Conv3d and x.is_contiguous() \
-                    and after.pre_supported(x.shape):
+                    and not _has_hooks(m, nxt, after) and after.pre_supported(x.shape):
                 # BN -> ReLU -> conv (Conv2Plus1D's mid tensor, resnet.py:46-52): the convolution applies the affine +
                 # ReLU while it reads the raw tensor; the normalised tensor is never written or read back
                 handle, coef = m(x, stats=stats, defer=True)
