@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 // The same sum for FEW slices and a large slab (the small-voxel layers: 2-4 slices of a 17-21 MB gradient): one block per
-// output channel reads its [taps][Cpad] row of every slice with 16-byte loads (coalesced), adds the slices in order -- the
-// order slab_sum_kernel uses for up to 8 slices, so the bits are the same -- and writes dw[co][ci][tap] through an LDS
+// output channel reads its [taps][Cpad] row of every slice with 16-byte loads (coalesced), adds the slices in order (up to 8
+// slices that is also slab_sum_kernel's order: the same bits) and writes dw[co][ci][tap] through an LDS
 // transpose as whole contiguous rows (slab_sum_kernel's 4-byte writes at stride `taps` made it run at 1 TB/s).
 __global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                             int M, int Cin, int taps, int Cpad, int slices) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restr
 // launches the slab sum that fits the geometry (same result bits either way)
 int slab_sum(const float* slabs, float* dw, int M, int Cin, int taps, int Cpad, int slices, hipStream_t stream) {
     const size_t row_bytes = (size_t)taps * Cpad * sizeof(float);
-    if (slices <= 8 && row_bytes <= 64 * 1024 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && !ZSV_KNOB(NO_SLAB_SUM_ROWS)) {
+    if (slices <= 32 && (long)M * slices <= 16384 && row_bytes <= 64 * 1024 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && !ZSV_KNOB(NO_SLAB_SUM_ROWS)) {
         static const hipError_t attr = hipFuncSetAttribute((const void*)slab_sum_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (attr != hipSuccess) return ZSV_E_LAUNCH;
         hipLaunchKernelGGL(slab_sum_rows_kernel, dim3((unsigned)M), dim3(256), row_bytes, stream, slabs, dw, M, Cin, taps, Cpad, slices);
