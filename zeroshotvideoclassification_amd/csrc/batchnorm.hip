@@ -112,13 +112,15 @@ __global__ void bn_finalize_train_kernel(const double* __restrict__ part, int C,
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                          float momentum, float eps, float* __restrict__ scale,
                                          float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x;                      // one 64-lane wave per channel (as bn_bwd_finalize_kernel)
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < slices; ++k) {
+    for (int k = threadIdx.x; k < slices; k += 64) {
         s1 += part[(size_t)c * slices + k];
         s2 += part[(size_t)(C + c) * slices + k];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (threadIdx.x != 0) return;
     const double K = pivot_src ? (double)pivot_src[(size_t)c * S] : 0.0;
     const double dmean = s1 / count;                 // mean - K
     const double mean = K + dmean;
@@ -305,13 +307,18 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, i
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
                                        float* __restrict__ ck, const float* __restrict__ beta,
                                        float* __restrict__ csh) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // one 64-lane wave per channel: lane l adds slices l, l + 64, ... in order, then the lanes are combined by xor-shuffles -- a
+    // fixed order (bitwise reproducible); a single thread walking up to ~35 slices with dependent adds took 16 us per launch,
+    // 37 launches per step on the backward's critical path
+    const int c = blockIdx.x;
     double sg = 0.0, sgx = 0.0;
-    for (int k = 0; k < slices; ++k) {
+    for (int k = threadIdx.x; k < slices; k += 64) {
         sg += part[(size_t)c * slices + k];
         sgx += part[(size_t)(C + c) * slices + k];
     }
+    sg = wave_sum(sg);
+    sgx = wave_sum(sgx);
+    if (threadIdx.x != 0) return;
     if (dgamma) dgamma[c] = (float)sgx;
     if (dbeta) dbeta[c] = (float)sg;
     const double g = gamma ? (double)gamma[c] : 1.0;
@@ -456,7 +463,7 @@ extern "C" int zsv_bn_fwd_train_stats(const float* x, int32_t N, int32_t C, int3
     } else {
         hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
         if ((st = launch_status())) return st;
-        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
+        hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C,
                            slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
                            momentum, eps, w.scale, w.shift);
     }
@@ -490,7 +497,7 @@ extern "C" int zsv_bn_fwd_train_coeffs(const float* x, int32_t N, int32_t C, int
     }
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, slices), dim3(256), 0, stream, x, N, C, S, slices, w.part);
     if ((st = launch_status())) return st;
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C,
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C,
                        slices, (double)N * S, pivot_src, S, gamma, beta, save_mean, save_invstd, running_mean, running_var,
                        momentum, eps, coef, coef + coef_pitch);
     return launch_status();
@@ -533,7 +540,7 @@ extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
     if ((st = launch_status())) return st;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, (const double*)w.part, C, slices,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C, slices,
                        (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
     if ((st = launch_status())) return st;
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
