@@ -30,18 +30,18 @@ from .layers import AdaptiveAvgPool3d, BatchNorm3d, Conv3d, Linear, ReLU
 __all__ = ["r3d_18", "mc3_18", "r2plus1d_18"]
 
 
-def _call(m: nn.Module, x: Tensor, want_stats: bool):
-    """Run a conv-like child; with ``want_stats`` also fetch the BatchNorm partial statistics its
-    (last) convolution accumulated in the kernel epilogue."""
-    if want_stats and isinstance(m, (Conv3d, _FusedSequential)):
-        return m(x, want_stats=True)
-    return m(x), None
-
-
 def _has_hooks(*mods: nn.Module) -> bool:
     """A forward (pre-)hook on one of the modules of a `BatchNorm -> ReLU -> conv` triple must see what the reference's module
     would hand it (the normalised tensor, the activated tensor): such a triple takes the separate passes, not the fold."""
     return any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
+
+def _call(m: nn.Module, x: Tensor, want_stats: bool):
+    """Run a conv-like child; with ``want_stats`` also fetch the BatchNorm partial statistics its
+    (last) convolution accumulated in the kernel epilogue."""
+    if want_stats and isinstance(m, (Conv3d, _FusedSequential)) and not _has_hooks(m):
+        return m(x, want_stats=True)
+    return m(x), None                  # (a hooked module is called the plain way: its hooks see a tensor, not (y, statistics))
 
 
 def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
@@ -55,7 +55,7 @@ def _run_chain(mods: Sequence[nn.Module], x: Tensor, want_stats: bool = False):
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         if isinstance(m, BatchNorm3d):
-            relu = isinstance(nxt, nn.ReLU)
+            relu = isinstance(nxt, nn.ReLU) and not _has_hooks(m, nxt)      # hooked: BatchNorm and ReLU run (and are observed) one by one
             after = mods[i + 2] if (relu and i + 2 < n) else None
             if relu and m.training and m.momentum is not None and type(after) is Conv3d and x.is_contiguous() \
                     and not _has_hooks(m, nxt, after) and after.pre_supported(x.shape):
