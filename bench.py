@@ -48,7 +48,7 @@ T_START = time.perf_counter()
 CLIPS_PER_GPU = 22
 FRAMES, SIZE = 16, 112
 FP32_MFMA_PEAK_TFLOPS = 157.3
-DEFAULT_TIMEOUT_S = 420.0
+DEFAULT_TIMEOUT_S = 600.0
 # S1 of SURVEY section 2a: Conv3d(64, 144, (1,3,3), stride 1, pad (0,1,1)) on 16x56x56
 S1_GEOMETRY = dict(Cin=64, Cout=144, kT=1, kH=3, kW=3, sT=1, sH=1, sW=1, Ti=16, Hi=56, Wi=56)
 # the dominant forward kernel per network: geometry (for the HIP-event timer), label, launches per step;
