@@ -312,6 +312,44 @@ int zsv_adam_multi_scaled(const zsv_adam_tensor* table_device, int32_t count, in
 int zsv_scaler_update(zsv_scaler_state* state_device, float growth_factor, float backoff_factor,
                       int32_t growth_interval, void* stream);
 
+/* ---- weight panels packed ahead of the call ---------------------------------------------------------------------------
+ * Every forward / dgrad entry point above first re-lays its weights out (a "panel": the direct kernel's [block][tap][16][m]
+ * image, the Winograd kernels' transformed weights, the stride-2 dgrad's tap-major image) in a small launch of its own: 76
+ * launches and 1.1-1.3 ms per R(2+1)D-18 training step (profiles/r03_pack_launches_cost.txt), although the weights change once
+ * per step.  A caller that knows when they change can keep the panels: query the panel size, ask for the job that fills it,
+ * run ALL jobs of a step in one zsv_pack_multi launch, and call the *_panel forms, which skip the pack launch.
+ * `direction` 0 = forward, 1 = input gradient; `extras` != 0 = the forward call carries a bias / ReLU / residual / statistics
+ * (some geometries then take another kernel and so another panel).  *panel_bytes = 0: this geometry has no single panel
+ * (3-channel stems, class-by-class strided gradients): use the ordinary entry points.  The job holds raw pointers (w, panel):
+ * it stays valid while those allocations do.  Panels depend on the ZSV_* switches: re-query after zsv_reload_knobs(). */
+typedef struct zsv_pack_job {
+    int32_t kind;            /* 0 direct kernel, 1 Winograd F(2,3), 2 Winograd F(4,3), 3 stride-2 input gradient */
+    int32_t reserved;
+    int64_t total;           /* elements of the panel */
+    int64_t first_block;     /* filled by the caller: running sum of ceil(total / 1024) over the preceding jobs of the table */
+    const float* w;
+    float* out;
+    int64_t l[2];            /* kind-specific strides */
+    int32_t i[20];           /* kind-specific integers */
+} zsv_pack_job;
+int zsv_conv3d_panel_query(const zsv_conv_desc* d, int32_t direction, int32_t extras, size_t* panel_bytes);
+int zsv_conv3d_panel_job(const zsv_conv_desc* d, int32_t direction, int32_t extras, const float* w, void* panel,
+                         size_t panel_bytes, zsv_pack_job* job);
+/* one launch for `count` jobs (device array sorted by first_block; total_blocks = sum of ceil(total / 1024)) */
+int zsv_pack_multi(const zsv_pack_job* jobs_device, int32_t count, int64_t total_blocks, void* stream);
+/* the entry points above with the panel supplied (packed by zsv_pack_multi from this call's job): no pack launch */
+int zsv_conv3d_fwd_full_panel(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                              const float* residual, float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles,
+                              void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes);
+int zsv_conv3d_fwd_pre_panel(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
+                             const float* w, float* y, float* bn_partials, int32_t stat_tiles, void* workspace,
+                             size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes);
+int zsv_conv3d_dgrad_add_panel(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+                               void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes);
+int zsv_conv3d_dgrad_add_strided_panel(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int32_t st,
+                                       int32_t sh, int32_t sw, float* dx, void* workspace, size_t workspace_bytes,
+                                       void* stream, const void* panel, size_t panel_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -690,3 +690,56 @@ def test_forward_hooks_see_the_reference_tensors():
     assert torch.equal(act, torch.relu(bn))
     m = bn.mean(dim=(0, 2, 3, 4))
     assert (m - pair[1].bias.detach()).abs().max().item() < 1e-4     # normalised: per-channel mean = beta
+
+
+def test_weight_panel_cache_is_the_same_bits_and_follows_the_weights(monkeypatch):
+    """ops._PanelCache: every (weight, geometry, direction) keeps its packed panel; when the optimizer has changed the weights the
+    first convolution of the next step re-packs ALL panels in one zsv_pack_multi launch and the calls skip their pack launches.
+    Three Adam steps with the cache equal three steps without it (ZSV_NO_PANEL_CACHE=1) bit for bit -- loss, every gradient, every
+    updated parameter -- and a weight written behind autograd's back is picked up after _lib.note_raw_write()."""
+    from zeroshotvideoclassification_amd import _lib, ops
+    g, model, weights = build("r2plus1d_small")
+    x, z = case_inputs(g)
+    xd, zd = x.to(DEV), z.to(DEV)
+
+    def three_steps():
+        model.load_state_dict(weights)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        out = []
+        for _ in range(3):
+            y, loss = train.train_step(model, opt, torch.nn.MSELoss(), xd, zd)
+            out.append((y.clone(), loss.clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        return out, {k: v.clone() for k, v in model.state_dict().items()}
+
+    ops.invalidate_panels()
+    a, sa = three_steps()
+    cache = ops._PANEL_CACHES[torch.device(DEV).index or 0]
+    live = [e for e in cache.entries.values() if e is not None]
+    assert len(live) >= 60                                    # forward + input-gradient panels of the 37 convolutions (stems have none)
+    repacks_before = cache.repacks
+    three_steps()
+    # steady state: load_state_dict + 3 optimizer steps = at most 4 weight versions -> a handful of multi-pack launches, not 74 per step
+    assert cache.repacks - repacks_before <= 8
+    monkeypatch.setenv("ZSV_NO_PANEL_CACHE", "1")
+    b, sb = three_steps()
+    monkeypatch.delenv("ZSV_NO_PANEL_CACHE")
+    for (ya, la, ga), (yb, lb, gb) in zip(a, b):
+        assert torch.equal(ya, yb) and torch.equal(la, lb)
+        assert sorted(ga) == sorted(gb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    # a raw write (no version bump) followed by note_raw_write(): the next forward uses the new weights
+    model.load_state_dict(weights)
+    model.eval()
+    with torch.no_grad():
+        y0 = train.embed(model, xd).clone()
+        w = model.model.layer1[0].conv1[0][0].weight
+        w.data.mul_(1.5)
+        _lib.note_raw_write()
+        y1 = train.embed(model, xd).clone()
+        monkeypatch.setenv("ZSV_NO_PANEL_CACHE", "1")
+        y1_ref = train.embed(model, xd).clone()
+    assert not torch.equal(y0, y1) and torch.equal(y1, y1_ref)

@@ -1290,3 +1290,80 @@ def test_conv3d_winograd_virtual_width(case, monkeypatch):
     close(y, y2.double(), rtol=1e-5, what="virtual width vs previous kernel, forward")
     close(dx, dx2.double(), rtol=1e-5, what="virtual width vs previous kernel, dgrad")
     assert not torch.equal(y, y2) and not torch.equal(dx, dx2), "the two paths should not be the same kernel"
+
+
+PANEL_CASES = [
+    # name, x shape, w shape, stride, padding
+    ("winograd_f43", (3, 64, 4, 24, 24), (144, 64, 1, 3, 3), 1, (0, 1, 1)),
+    ("virtual_width_7", (6, 96, 2, 7, 7), (200, 96, 1, 3, 3), 1, (0, 1, 1)),
+    ("temporal_winograd", (3, 144, 8, 16, 16), (64, 144, 3, 1, 1), 1, (1, 0, 0)),
+    ("two_frames_dense", (5, 130, 2, 7, 7), (70, 130, 3, 1, 1), 1, (1, 0, 0)),
+    ("strided_spatial", (3, 64, 4, 28, 28), (230, 64, 1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("strided_temporal", (3, 230, 8, 14, 14), (128, 230, 3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ("pointwise", (4, 64, 4, 14, 14), (128, 64, 1, 1, 1), 1, (0, 0, 0)),
+    ("full_333", (2, 32, 6, 12, 16), (48, 32, 3, 3, 3), 1, (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", PANEL_CASES, ids=[c[0] for c in PANEL_CASES])
+def test_weight_panels_packed_ahead_of_the_call(case):
+    """C ABI: zsv_conv3d_panel_query / _panel_job / zsv_pack_multi / zsv_conv3d_*_panel.  The panel packed by the multi-job launch
+    from the call's own job, fed to the *_panel entry point, gives the bits of the ordinary entry point (which packs per call):
+    forward (plain and with a bias + ReLU) and input gradient; several jobs share one table / one launch."""
+    import ctypes
+    from zeroshotvideoclassification_amd import _lib
+    name, xs, ws_, stride, pad = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn(*xs, generator=g).to(DEV)
+    w = (torch.randn(*ws_, generator=g) / np.sqrt(np.prod(ws_[1:]))).to(DEV)
+    bias = torch.randn(ws_[0], generator=g).to(DEV)
+    d = ops.conv_desc(xs, ws_, stride, pad)
+    y_shape = (d.N, d.Cout, d.To, d.Ho, d.Wo)
+    dy = torch.randn(*y_shape, generator=g).to(DEV)
+    variants = [(0, 0), (0, 1), (1, 0)]                       # (direction, extras)
+    jobs, panels = [], {}
+    for direction, extras in variants:
+        nb = ctypes.c_size_t(0)
+        _lib.check(lib.zsv_conv3d_panel_query(ctypes.byref(d), direction, extras, ctypes.byref(nb)), "query")
+        assert nb.value > 0, (name, direction, extras)
+        panel = torch.full((nb.value,), 0xFF, dtype=torch.uint8, device=DEV)
+        job = _lib.PackJob()
+        _lib.check(lib.zsv_conv3d_panel_job(ctypes.byref(d), direction, extras, w.data_ptr(), panel.data_ptr(), nb.value, ctypes.byref(job)), "job")
+        assert job.total * 4 <= nb.value and job.w == w.data_ptr() and job.out == panel.data_ptr()
+        jobs.append(job)
+        panels[(direction, extras)] = panel
+    first, raw = 0, bytearray()
+    for job in jobs:
+        job.first_block = first
+        first += (job.total + 1023) // 1024
+        raw += bytes(job)
+    table = torch.frombuffer(raw, dtype=torch.uint8).to(DEV)
+    _lib.check(lib.zsv_pack_multi(table.data_ptr(), len(jobs), first, None), "pack_multi")
+    nf, nd = lib.zsv_conv3d_fwd_workspace_bytes(ctypes.byref(d)), lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(int(nf), int(nd), 16), dtype=torch.uint8, device=DEV)
+    for extras in (0, 1):
+        y_ref, y = torch.empty(y_shape, device=DEV), torch.empty(y_shape, device=DEV)
+        b = bias.data_ptr() if extras else None
+        _lib.check(lib.zsv_conv3d_fwd_full(ctypes.byref(d), x.data_ptr(), w.data_ptr(), b, None, y_ref.data_ptr(), extras, None, 0, ws.data_ptr(), nf, None), "fwd")
+        p = panels[(0, extras)]
+        _lib.check(lib.zsv_conv3d_fwd_full_panel(ctypes.byref(d), x.data_ptr(), w.data_ptr(), b, None, y.data_ptr(), extras, None, 0, ws.data_ptr(), nf, None,
+                                                 p.data_ptr(), p.numel()), "fwd panel")
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), (name, "forward", extras)
+    dx_ref, dx = torch.empty(xs, device=DEV), torch.empty(xs, device=DEV)
+    _lib.check(lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), w.data_ptr(), dx_ref.data_ptr(), ws.data_ptr(), nd, None), "dgrad")
+    p = panels[(1, 0)]
+    _lib.check(lib.zsv_conv3d_dgrad_add_panel(ctypes.byref(d), dy.data_ptr(), w.data_ptr(), None, dx.data_ptr(), ws.data_ptr(), nd, None, p.data_ptr(), p.numel()),
+               "dgrad panel")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref), (name, "dgrad")
+    ref = F.conv3d(x.double().cpu(), w.double().cpu(), stride=stride, padding=pad)
+    close(y, F.relu(ref + bias.double().cpu().view(1, -1, 1, 1, 1)), what="forward + bias + relu")
+    # a too-small panel is refused, a stem has no panel
+    assert lib.zsv_conv3d_fwd_full_panel(ctypes.byref(d), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), 0, None, 0, ws.data_ptr(), nf, None,
+                                         panels[(0, 0)].data_ptr(), 16) != 0
+    ds = ops.conv_desc((2, 3, 4, 32, 32), (45, 3, 1, 7, 7), (1, 2, 2), (0, 3, 3))
+    nb = ctypes.c_size_t(1)
+    _lib.check(lib.zsv_conv3d_panel_query(ctypes.byref(ds), 0, 0, ctypes.byref(nb)), "query stem")
+    assert nb.value == 0

@@ -88,7 +88,21 @@ SIGNATURES = {
     "zsv_adam_multi_scaled": (c_int, [_P, c_int32, c_int64, c_float, c_float, c_float, c_float, _P, _P]),
     "zsv_scaler_update": (c_int, [_P, c_float, c_float, c_int32, _P]),
     "zsv_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int32, _P]),
+    "zsv_conv3d_panel_query": (c_int, [POINTER(ConvDesc), c_int32, c_int32, POINTER(c_size_t)]),
+    "zsv_conv3d_panel_job": (c_int, [POINTER(ConvDesc), c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "zsv_pack_multi": (c_int, [_P, c_int32, c_int64, _P]),
+    "zsv_conv3d_fwd_full_panel": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, c_int32, _P, c_size_t, _P, _P, c_size_t]),
+    "zsv_conv3d_fwd_pre_panel": (c_int, [POINTER(ConvDesc), _P, _P, c_int32, _P, _P, _P, c_int32, _P, c_size_t, _P, _P, c_size_t]),
+    "zsv_conv3d_dgrad_add_panel": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t, _P, _P, c_size_t]),
+    "zsv_conv3d_dgrad_add_strided_panel": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P, _P,
+                                                   c_size_t]),
 }
+
+
+class PackJob(Structure):
+    """Mirror of ``zsv_pack_job`` (include/zsv_hip.h): one weight-panel pack launch written down for ``zsv_pack_multi``."""
+    _fields_ = [("kind", c_int32), ("reserved", c_int32), ("total", c_int64), ("first_block", c_int64), ("w", c_void_p),
+                ("out", c_void_p), ("l", c_int64 * 2), ("i", c_int32 * 20)]
 
 _lock = threading.Lock()
 _lib = None
@@ -97,6 +111,11 @@ _lib = None
 # The library snapshots its ZSV_* switches at load (csrc/knobs.h).  Tests and A/B tools flip them with os.environ inside
 # a live process: an audit hook notices such a write and the next ``load()`` -- every op goes through it -- re-reads them.
 _knobs_dirty = False
+_knob_generation = 0          # bumped whenever the library re-read its switches (cached weight panels depend on them)
+
+
+def knob_generation() -> int:
+    return _knob_generation
 
 
 def _watch_environment(event, args):
@@ -107,12 +126,13 @@ def _watch_environment(event, args):
 
 def load() -> ctypes.CDLL:
     """Load (once) and type the library; raises ``RuntimeError`` when it has not been built."""
-    global _lib, _knobs_dirty
+    global _lib, _knobs_dirty, _knob_generation
     if _lib is not None:
         if _knobs_dirty:
             with _lock:
                 if _knobs_dirty:
                     _knobs_dirty = False
+                    _knob_generation += 1
                     _lib.zsv_reload_knobs()
         return _lib
     with _lock:
@@ -146,12 +166,20 @@ def check(status: int, what: str) -> None:
 # Anything that caches values derived from parameters / buffers (``inference.engine_for``) keys on this
 # counter too; every such writer calls ``note_raw_write()``.
 _raw_write_generation = 0
+_raw_param_generation = 0       # ... of which: writes that touched PARAMETERS (cached weight panels key on this one only)
 
 
-def note_raw_write() -> None:
-    global _raw_write_generation
+def note_raw_write(parameters: bool = True) -> None:
+    """``parameters=False``: only buffers were written (BatchNorm running statistics, every training forward)."""
+    global _raw_write_generation, _raw_param_generation
     _raw_write_generation += 1
+    if parameters:
+        _raw_param_generation += 1
 
 
 def raw_write_generation() -> int:
     return _raw_write_generation
+
+
+def raw_param_generation() -> int:
+    return _raw_param_generation

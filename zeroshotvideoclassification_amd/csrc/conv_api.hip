@@ -172,7 +172,7 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
             p.ksplit = ks;
             p.slab_elems = (int)out_elems;
             st = igemm_tap(p, w, 0, 0, x, nullptr, y, workspace, wbytes, slabs, (hipStream_t)stream);
-            if (st || ks <= 1) return st;
+            if (st || ks <= 1 || panel_stop()) return st;
             return splitk_reduce(slabs, ks, out_elems, d2.Cout, p.oS, nullptr, 0, y, (hipStream_t)stream);
         }
     }
@@ -196,9 +196,10 @@ extern "C" int zsv_conv3d_fwd_full(const zsv_conv_desc* d, const float* x, const
         p.ksplit = ks;
         p.slab_elems = (int)out_elems;
         st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, bias, y, workspace, wbytes, slabs, (hipStream_t)stream);
-        if (st || ks <= 1) return st;
+        if (st || ks <= 1 || panel_stop()) return st;
         return splitk_reduce(slabs, ks, out_elems, d->Cout, p.oS, bias, fuse_relu ? 1 : 0, y, (hipStream_t)stream);
     }
+    if (g_panel.mode != PANEL_NONE) return panel_stop() ? ZSV_OK : ZSV_E_UNSUPPORTED;      // (no weight panel on this path: jobs stays 0)
     const bool avec = (p.K % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     return igemm_generic(p, avec, w, x, bias, y, (hipStream_t)stream);
 }
@@ -246,7 +247,7 @@ extern "C" int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const 
     p.ksplit = ks;
     p.slab_elems = (int)out_elems;
     st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, x, nullptr, y, workspace, wbytes, slabs, (hipStream_t)stream);
-    if (st || ks <= 1) return st;
+    if (st || ks <= 1 || panel_stop()) return st;
     return splitk_reduce(slabs, ks, out_elems, d->Cout, p.oS, nullptr, 0, y, (hipStream_t)stream);
 }
 
@@ -317,6 +318,11 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
     if (need > 0 && (!workspace || workspace_bytes < need)) return ZSV_E_WORKSPACE;
     float* slabs = ks > 1 ? (float*)((char*)workspace + wbytes) : nullptr;
     IgemmParams p;
+    if (g_panel.mode != PANEL_NONE && (d->sT != 1 || d->sH != 1 || d->sW != 1)) {
+        // class-by-class launches pack one panel per residue class into the same workspace: no single panel to keep
+        if (g_panel.mode == PANEL_QUERY) { g_panel.jobs = 2; return ZSV_OK; }
+        return ZSV_E_UNSUPPORTED;
+    }
     // residue classes that see no tap (e.g. 7 of the 8 classes of a 1x1x1 stride-2 shortcut) are
     // exactly zero: clear dx once instead of launching a kernel per empty class
     bool any_empty = false;
@@ -340,11 +346,12 @@ extern "C" int zsv_conv3d_dgrad_add(const zsv_conv_desc* d, const float* dy, con
                     st = igemm_tap(p, w, p.a_m_stride, p.a_c_stride, dy, nullptr, dx, workspace, wbytes, slabs,
                                    (hipStream_t)stream);
                 } else {
+                    if (g_panel.mode != PANEL_NONE) return panel_stop() ? ZSV_OK : ZSV_E_UNSUPPORTED;
                     st = igemm_generic(p, false, w, dy, nullptr, dx, (hipStream_t)stream);
                 }
                 if (st) return st;
             }
-    if (ks > 1) return splitk_reduce(slabs, ks, out_elems, d->Cin, p.oS, nullptr, 0, dx, (hipStream_t)stream);
+    if (ks > 1 && !panel_stop()) return splitk_reduce(slabs, ks, out_elems, d->Cin, p.oS, nullptr, 0, dx, (hipStream_t)stream);
     return ZSV_OK;
 }
 
@@ -386,4 +393,79 @@ extern "C" int zsv_linear_dgrad(const float* dy, const float* w, float* dx, int3
                                 int32_t out_features, void* workspace, size_t workspace_bytes, void* stream) {
     const zsv_conv_desc d = linear_desc(rows, in_features, out_features);
     return zsv_conv3d_dgrad(&d, dy, w, dx, workspace, workspace_bytes, stream);
+}
+
+
+// ---- weight panels kept by the caller (zsv_hip.h) ------------------------------------------------------------------------------
+// query / job run the ordinary entry point with the thread-local panel context set (conv_params.h): the path that would pack a
+// panel reports its size / writes the pack launch down and returns before anything is launched; x / y / workspace are never touched.
+namespace {
+struct PanelScope {
+    PanelScope(int mode, void* ptr, size_t bytes) { g_panel = PanelCtx{mode, ptr, bytes, 0, 0, {}}; }
+    ~PanelScope() { g_panel.mode = PANEL_NONE; g_panel.ptr = nullptr; }
+};
+float* const kDummy = reinterpret_cast<float*>(0x1000);      // non-null, 16-byte aligned, never dereferenced in query / record mode
+int panel_probe(const zsv_conv_desc* d, int32_t direction, int32_t extras, const float* w) {
+    if (direction == 0)
+        return zsv_conv3d_fwd_full(d, kDummy, w, extras ? kDummy : nullptr, nullptr, kDummy, 0, nullptr, 0, kDummy, ~(size_t)0 >> 1, nullptr);
+    return zsv_conv3d_dgrad_add(d, kDummy, w, nullptr, kDummy, kDummy, ~(size_t)0 >> 1, nullptr);
+}
+}  // namespace
+
+extern "C" int zsv_conv3d_panel_query(const zsv_conv_desc* d, int32_t direction, int32_t extras, size_t* panel_bytes) {
+    if (!panel_bytes) return ZSV_E_NULL;
+    *panel_bytes = 0;
+    int st = conv_check(d);
+    if (st) return st;
+    if (direction != 0 && direction != 1) return ZSV_E_BAD_SHAPE;
+    PanelScope scope(PANEL_QUERY, nullptr, 0);
+    st = panel_probe(d, direction, extras, kDummy);
+    if (st) return st;
+    *panel_bytes = g_panel.jobs == 1 ? g_panel.need : 0;
+    return ZSV_OK;
+}
+
+extern "C" int zsv_conv3d_panel_job(const zsv_conv_desc* d, int32_t direction, int32_t extras, const float* w, void* panel,
+                                    size_t panel_bytes, zsv_pack_job* job) {
+    if (!w || !panel || !job) return ZSV_E_NULL;
+    int st = conv_check(d);
+    if (st) return st;
+    if (direction != 0 && direction != 1) return ZSV_E_BAD_SHAPE;
+    PanelScope scope(PANEL_RECORD, panel, panel_bytes);
+    st = panel_probe(d, direction, extras, w);
+    if (st) return st;
+    if (g_panel.jobs != 1) return ZSV_E_UNSUPPORTED;
+    *job = g_panel.job;
+    return ZSV_OK;
+}
+
+extern "C" int zsv_conv3d_fwd_full_panel(const zsv_conv_desc* d, const float* x, const float* w, const float* bias,
+                                         const float* residual, float* y, int fuse_relu, float* bn_partials, int32_t stat_tiles,
+                                         void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes) {
+    if (!panel) return ZSV_E_NULL;
+    PanelScope scope(PANEL_LAUNCH_ONLY, const_cast<void*>(panel), panel_bytes);
+    return zsv_conv3d_fwd_full(d, x, w, bias, residual, y, fuse_relu, bn_partials, stat_tiles, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_fwd_pre_panel(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
+                                        const float* w, float* y, float* bn_partials, int32_t stat_tiles, void* workspace,
+                                        size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes) {
+    if (!panel) return ZSV_E_NULL;
+    PanelScope scope(PANEL_LAUNCH_ONLY, const_cast<void*>(panel), panel_bytes);
+    return zsv_conv3d_fwd_pre(d, x, pre_coef, coef_pitch, w, y, bn_partials, stat_tiles, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_dgrad_add_panel(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+                                          void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes) {
+    if (!panel) return ZSV_E_NULL;
+    PanelScope scope(PANEL_LAUNCH_ONLY, const_cast<void*>(panel), panel_bytes);
+    return zsv_conv3d_dgrad_add(d, dy, w, add, dx, workspace, workspace_bytes, stream);
+}
+
+extern "C" int zsv_conv3d_dgrad_add_strided_panel(const zsv_conv_desc* d, const float* dy, const float* w, const float* sub, int32_t st,
+                                                  int32_t sh, int32_t sw, float* dx, void* workspace, size_t workspace_bytes,
+                                                  void* stream, const void* panel, size_t panel_bytes) {
+    if (!panel) return ZSV_E_NULL;
+    PanelScope scope(PANEL_LAUNCH_ONLY, const_cast<void*>(panel), panel_bytes);
+    return zsv_conv3d_dgrad_add_strided(d, dy, w, sub, st, sh, sw, dx, workspace, workspace_bytes, stream);
 }

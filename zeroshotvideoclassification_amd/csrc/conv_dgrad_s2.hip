@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "conv_params.h"
 #include "knobs.h"
+#include "pack_bodies.h"
 
 namespace zsv {
 
@@ -55,15 +56,8 @@ template <> struct S2Kind<KIND_T> { static constexpr int NTAP = 3, NCLS = 2, NSH
 // Wp[((chunk * NTAP + tap) * 8 + co % 8) * Mp + m] = W[co][m][tap], co = 8 * chunk + ..., zero in the padding
 __global__ __launch_bounds__(256) void dgrad_s2_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp, int M, int Mp,
                                                             int Cout, int ntap, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int m = (int)(i % Mp);
-        long r = i / Mp;
-        const int k = (int)(r % 8);
-        r /= 8;
-        const int tap = (int)(r % ntap);
-        const int co = (int)(r / ntap) * 8 + k;
-        Wp[i] = (m < M && co < Cout) ? W[((size_t)co * M + m) * ntap + tap] : 0.f;
-    }
+    const PackS2Args a = {M, Mp, Cout, ntap};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Wp[i] = pack_s2_value(a, W, i);
 }
 
 // X4: dy clips are whole 16-byte pieces (S % 4 == 0; temporal form: frames too): one 16-byte DMA instruction per image row
@@ -365,13 +359,22 @@ int dgrad_s2(const zsv_conv_desc* d, const float* dy, const float* w, const floa
     p.ksplit = pl.ks; p.chunks_per_split = pl.cps;
     p.slab_elems = (int)((long)d->N * d->Cin * p.oS);
     p.sub = sub; p.sub_st = sub ? sub_st : 1; p.subT = sub ? (d->Ti + sub_st - 1) / sub_st : 0;
-    float* wp = (float*)workspace;
+    float* wp;
+    int pst;
+    if (!panel_place(s2_panel_bytes(d, pl), workspace, wp, pst)) return pst;
     float* slabs = (float*)((char*)workspace + s2_panel_bytes(d, pl));
     const long total = (long)pl.nchunks * ntap * 8 * p.Mp;
-    long pb = (total + 255) / 256;
-    if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(dgrad_s2_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, wp, p.M, p.Mp, p.Cout, ntap, total);
-    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (g_panel.mode == PANEL_RECORD) {
+        pack_job_s2(g_panel.job, PackS2Args{p.M, p.Mp, p.Cout, ntap}, w, wp, total);
+        g_panel.jobs++;
+        return ZSV_OK;
+    }
+    if (g_panel.mode != PANEL_LAUNCH_ONLY) {
+        long pb = (total + 255) / 256;
+        if (pb > 4096) pb = 4096;
+        hipLaunchKernelGGL(dgrad_s2_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, wp, p.M, p.Mp, p.Cout, ntap, total);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    }
     float* out = pl.ks > 1 ? slabs : dx;
     int st;
     if (pl.kind == KIND_HW) st = pl.bn == 128 ? s2_launch_x<128, KIND_HW>(x4, p, wp, dy, out, stream) : s2_launch_x<64, KIND_HW>(x4, p, wp, dy, out, stream);

@@ -66,6 +66,33 @@ __host__ __device__ inline long t2_weight_offset(int co2, int c2, int cin) {
     return ((long)(co2 >> 1) * cin + (c2 >> 1)) * 3 + ((c2 & 1) - (co2 & 1) + 1);
 }
 
+// ---- weight panels supplied by the caller (zsv_hip.h: zsv_conv3d_*_panel) -------------------------------------------------
+// The public entry points keep ONE dispatch: the *_panel / query / job forms set this thread-local context and call the
+// ordinary entry point; the function that would launch a pack kernel looks at it.
+enum { PANEL_NONE = 0, PANEL_LAUNCH_ONLY = 2, PANEL_RECORD = 3, PANEL_QUERY = 4 };
+struct PanelCtx {
+    int mode;
+    void* ptr;              // LAUNCH_ONLY / RECORD: the caller's panel
+    size_t bytes;
+    size_t need;            // QUERY: bytes of the panel this call would pack
+    int jobs;               // QUERY / RECORD: pack launches the call would make (> 1: not cacheable)
+    zsv_pack_job job;       // RECORD: the pack launch as a job of zsv_pack_multi
+};
+extern thread_local PanelCtx g_panel;
+inline bool panel_stop() { return g_panel.mode == PANEL_RECORD || g_panel.mode == PANEL_QUERY; }
+// Where the panel of this call lives: the caller's buffer or the head of the workspace.  false = stop here (status in `st`).
+inline bool panel_place(size_t need, void* workspace, float*& panel, int& st) {
+    PanelCtx& pc = g_panel;
+    st = ZSV_OK;
+    panel = (float*)workspace;
+    if (pc.mode == PANEL_QUERY) { pc.need = need; pc.jobs++; return false; }
+    if (pc.mode != PANEL_NONE) {
+        if (!pc.ptr || pc.bytes < need || (reinterpret_cast<uintptr_t>(pc.ptr) & 15) != 0) { st = ZSV_E_WORKSPACE; return false; }
+        panel = (float*)pc.ptr;
+    }
+    return true;
+}
+
 template <int X> struct LdPad { static constexpr int value = (X % 32 == 16) ? X : X + 16; };
 
 __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -29,6 +29,7 @@
 // 3-channel 7x7 stems stay on conv_igemm.hip.
 #include <stdlib.h>
 #include "conv_params.h"
+#include "pack_bodies.h"
 #include "knobs.h"
 
 namespace zsv {
@@ -38,27 +39,8 @@ namespace zsv {
 __global__ __launch_bounds__(256) void pack_weights_kernel(IgemmParams prm, const float* __restrict__ W,
                                                            float* __restrict__ Wp, int w_m_stride, int w_c_stride,
                                                            int Cpad, int Mp, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        // row = ((channel block * taps) + tap) * 16 + channel-in-block: all taps of a 16-channel
-        // block are consecutive chunks, so the gathered rows stay hot in L1/L2 across the taps
-        const int m = (int)(i % Mp);
-        const long rc = i / Mp;
-        const int blk = (int)(rc / 16);
-        const int cb = blk / prm.taps;
-        const int tap = blk - cb * prm.taps;
-        const int c = cb * 16 + (int)(rc % 16);
-        float v = 0.f;
-        if (m < prm.M && c < prm.gC && cb * 16 < Cpad) {
-            const int jt = tap / prm.nHW;
-            const int r = tap - jt * prm.nHW;
-            const int jh = r / prm.nW;
-            const int jw = r - jh * prm.nW;
-            const int tap_full = ((prm.k0T + prm.tsT * jt) * prm.kH + prm.k0H + prm.tsH * jh) * prm.kW + prm.k0W + prm.tsW * jw;
-            v = prm.t2_cin ? W[prm.dir > 0 ? t2_weight_offset(m, c, prm.t2_cin) : t2_weight_offset(c, m, prm.t2_cin)]
-                           : W[(size_t)m * w_m_stride + (size_t)c * w_c_stride + tap_full];
-        }
-        Wp[i] = v;
-    }
+    const PackTapArgs a = pack_tap_args(prm, w_m_stride, w_c_stride, Cpad, Mp);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Wp[i] = pack_tap_value(a, W, i);
 }
 
 // The same packing with coalesced traffic on both sides.  pack_weights_kernel walks Wp (m fastest) and so reads W at
@@ -562,10 +544,19 @@ int igemm_tap(const IgemmParams& prm_in, const float* W, int w_m_stride, int w_c
     const size_t need = ((size_t)prm.taps * Cpad + 16) * Mp * sizeof(float);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ZSV_E_WORKSPACE;
-    float* Wp = (float*)workspace;
+    float* Wp;
+    int pst;
+    if (!panel_place(need, workspace, Wp, pst)) return pst;
     const long total = ((long)prm.taps * Cpad + 16) * Mp;           // the 16 extra rows are zero
     const int rows_total = prm.taps * Cpad + 16;
-    if ((long)prm.M * prm.gC * prm.taps >= 65536 && prm.taps <= 27 && !ZSV_KNOB(NO_PACK_TILED)) {
+    if (g_panel.mode == PANEL_RECORD) {
+        pack_job_tap(g_panel.job, pack_tap_args(prm, w_m_stride, w_c_stride, Cpad, Mp), W, Wp, total);
+        g_panel.jobs++;
+        return ZSV_OK;
+    }
+    if (g_panel.mode == PANEL_LAUNCH_ONLY) {
+        // (the caller's panel was packed by zsv_pack_multi from this call's job)
+    } else if ((long)prm.M * prm.gC * prm.taps >= 65536 && prm.taps <= 27 && !ZSV_KNOB(NO_PACK_TILED)) {
         // (+1 channel block: the 16 trailing zero rows; c >= gC packs zeros)
         const int mt = prm.taps <= 9 ? 32 : 16;
         const dim3 grid((unsigned)(nblk + 1), (unsigned)((Mp + mt - 1) / mt));

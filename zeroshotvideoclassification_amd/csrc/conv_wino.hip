@@ -28,6 +28,7 @@
 #include "zsv_common.h"
 #include "zsv_hip.h"
 #include "knobs.h"
+#include "pack_bodies.h"
 
 namespace zsv {
 
@@ -65,27 +66,8 @@ struct WinoParams {
 // Up[(cb*R + r)*4 + pt][Mp][c%16] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
                                                         int C, int nblk, int R, long sm, long sc, int flip, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c16 = (int)(i % 16);
-        long r = i / 16;
-        const int m = (int)(r % Mp);
-        r /= Mp;
-        const int pt = (int)(r % 4);
-        r /= 4;
-        const int kh = (int)(r % R);
-        const int cb = (int)(r / R);
-        const int c = cb * 16 + c16;
-        float v = 0.f;
-        if (m < M && c < C) {
-            const float* g = W + (size_t)m * sm + (size_t)c * sc;
-            const int last = 3 * R - 1;
-            const int k0 = flip ? last - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? last - (3 * kh + 1) : 3 * kh + 1,
-                      k2 = flip ? last - (3 * kh + 2) : 3 * kh + 2;
-            const float g0 = g[k0], g1 = g[k1], g2 = g[k2];
-            v = pt == 0 ? g0 : pt == 1 ? 0.5f * ((g0 + g2) + g1) : pt == 2 ? 0.5f * ((g0 + g2) - g1) : g2;
-        }
-        Up[i] = v;
-    }
+    const PackWinoArgs a = {M, Mp, C, nblk, R, flip, sm, sc};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Up[i] = pack_wino_value<4>(a, W, i);
 }
 
 // TM = 16-row blocks per workgroup (rows = 16*TM: 64 for the gradients, 48 for the 144- and 288-channel forwards);
@@ -368,29 +350,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoParams prm, const
 // a second barrier per chunk separates the fragment reads of a chunk from the DMAs of the next one.
 __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict__ W, float* __restrict__ Up, int M, int Mp,
                                                          int C, int nblk, int R, long sm, long sc, int flip, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c16 = (int)(i % 16);
-        long r = i / 16;
-        const int m = (int)(r % Mp);
-        r /= Mp;
-        const int pt = (int)(r % 6);
-        r /= 6;
-        const int kh = (int)(r % R);
-        const int cb = (int)(r / R);
-        const int c = cb * 16 + c16;
-        float v = 0.f;
-        if (m < M && c < C) {
-            const float* g = W + (size_t)m * sm + (size_t)c * sc;
-            const int last = 3 * R - 1;
-            const int k0 = flip ? last - (3 * kh + 0) : 3 * kh + 0, k1 = flip ? last - (3 * kh + 1) : 3 * kh + 1,
-                      k2 = flip ? last - (3 * kh + 2) : 3 * kh + 2;
-            const double g0 = g[k0], g1 = g[k1], g2 = g[k2];          // (formed in double, rounded once)
-            const double u = pt == 0 ? g0 / 4 : pt == 1 ? -((g0 + g2) + g1) / 6 : pt == 2 ? -((g0 + g2) - g1) / 6
-                           : pt == 3 ? (g0 / 24 + g2 / 6) + g1 / 12 : pt == 4 ? (g0 / 24 + g2 / 6) - g1 / 12 : g2;
-            v = (float)u;
-        }
-        Up[i] = v;
-    }
+    const PackWinoArgs a = {M, Mp, C, nblk, R, flip, sm, sc};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Up[i] = pack_wino_value<6>(a, W, i);
 }
 
 #ifndef W4ABL
@@ -1466,14 +1427,23 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
     p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
-    float* up = (float*)workspace;
+    float* up;
+    int pst;
+    if (!panel_place(wino_bytes(d, M, C), workspace, up, pst)) return pst;
     const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
     const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
-    long pb = (total + 255) / 256;
-    if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip,
-                       total);
-    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (g_panel.mode == PANEL_RECORD) {
+        pack_job_wino(g_panel.job, f43 ? 6 : 4, PackWinoArgs{p.M, p.Mp, p.C, p.nblk, 1, flip, sm, sc}, w, up, total);
+        g_panel.jobs++;
+        return ZSV_OK;
+    }
+    if (g_panel.mode != PANEL_LAUNCH_ONLY) {
+        long pb = (total + 255) / 256;
+        if (pb > 4096) pb = 4096;
+        hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C, p.nblk, 1, sm, sc, flip,
+                           total);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    }
     if (f43) {
         if (pre_coef) return tm == 3 ? winot4_launch<3, true>(p, up, in, out, stream) : winot4_launch<4, true>(p, up, in, out, stream);
         return tm == 3 ? winot4_launch<3, false>(p, up, in, out, stream) : winot4_launch<4, false>(p, up, in, out, stream);
@@ -1515,17 +1485,26 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     p.ksplit = ks;
     p.chunks_per_split = (p.nblk * p.R + ks - 1) / ks;
     p.slab_elems = (long)d->N * M * p.S;
-    float* up = (float*)workspace;
+    float* up;
+    int pst;
+    if (!panel_place(wino_bytes(d, M, C), workspace, up, pst)) return pst;
     float* slabs = (float*)((char*)workspace + wino_bytes(d, M, C));
     if (ks > 1) { p.bias = nullptr; p.relu = 0; out = slabs; }         // bias / ReLU move to the ordered sum of the parts
     const bool f43 = wino_f43(d);
     p.u_bytes = (unsigned)wino_bytes(d, M, C);
     const long total = (long)p.nblk * p.R * (f43 ? 6 : 4) * 16 * p.Mp;
-    long pb = (total + 255) / 256;
-    if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C,
-                       p.nblk, p.R, sm, sc, flip, total);
-    if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    if (g_panel.mode == PANEL_RECORD) {
+        pack_job_wino(g_panel.job, f43 ? 6 : 4, PackWinoArgs{p.M, p.Mp, p.C, p.nblk, p.R, flip, sm, sc}, w, up, total);
+        g_panel.jobs++;
+        return ZSV_OK;
+    }
+    if (g_panel.mode != PANEL_LAUNCH_ONLY) {
+        long pb = (total + 255) / 256;
+        if (pb > 4096) pb = 4096;
+        hipLaunchKernelGGL(f43 ? wino4_pack_kernel : wino_pack_kernel, dim3((unsigned)pb), dim3(256), 0, stream, w, up, p.M, p.Mp, p.C,
+                           p.nblk, p.R, sm, sc, flip, total);
+        if (hipGetLastError() != hipSuccess) return ZSV_E_LAUNCH;
+    }
     const bool x4 = d->Wi % 4 == 0 && ZSV_KNOB(WINO_NO_X4) == nullptr;
     int st;
     if (p.Wv) {

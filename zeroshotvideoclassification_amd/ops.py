@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import os
 
-from ctypes import byref, c_void_p
+from ctypes import byref, c_size_t, c_void_p
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -195,6 +195,143 @@ class KernelTimer:
 KERNEL_TIMER: Optional[KernelTimer] = None
 
 
+# ---- weight panels kept across calls ------------------------------------------------------------------------------------
+# Every convolution entry point re-lays its weights out ("packs a panel") in a launch of its own: 76 launches, 1.1-1.3 ms per
+# R(2+1)D-18 training step (profiles/r03_pack_launches_cost.txt) for weights that change once per step.  Here every (weight,
+# geometry, direction) keeps its panel in a buffer of its own; when a call finds its weight changed -- the first convolution of a
+# step after the optimizer -- ALL stale panels (forward and input-gradient forms of every layer seen so far) are re-packed by ONE
+# zsv_pack_multi launch on the calling stream, and the calls run the *_panel entry points, which skip their pack launch.
+# "Changed" = the parameter's autograd version counter, its storage address, or `_lib.note_raw_write()` (kernels and `.data`
+# writes that bypass the counter: FusedAdam, load_weights, broadcast_state -- anything else that writes `weight.data` directly must
+# call `_lib.note_raw_write()` or `ops.invalidate_panels()`).  ZSV_NO_PANEL_CACHE=1 turns the cache off (every call packs, as before).
+class _Panel:
+    __slots__ = ("weight", "desc", "direction", "extras", "panel", "nbytes", "job", "version", "blocks")
+
+
+class _PanelCache:
+    def __init__(self, device):
+        import threading
+        self.device = device
+        self.entries = {}            # key -> _Panel (None: this geometry has no single panel)
+        self.knob_gen = _lib.knob_generation()
+        self.table = None            # (tuple of entry keys, device table, total blocks, keep-alive host bytes)
+        self.event = None            # recorded after the last multi-pack: consumers on another stream wait for it
+        self.stream = None
+        self.lock = threading.RLock()
+        self.repacks = 0             # multi-pack launches so far (tests / diagnostics)
+
+    @staticmethod
+    def _version(w):
+        return (w._version, w.data_ptr(), _lib.raw_param_generation())
+
+    def get(self, weight, d, direction, extras):
+        """The up-to-date panel tensor of this call, or None (not cacheable / cache disabled)."""
+        import weakref
+        with self.lock:
+            if self.knob_gen != _lib.knob_generation():          # the switches changed: layouts may have too
+                self.entries.clear()
+                self.table = None
+                self.knob_gen = _lib.knob_generation()
+            key = (id(weight), direction, extras) + d.key
+            e = self.entries.get(key, False)
+            if e is not False and e is not None and e.weight() is not weight:
+                e = False                                        # (the id was recycled by another tensor)
+            if e is False:
+                e = self._create(weight, d, direction, extras, weakref)
+                self.entries[key] = e
+                self.table = None
+            if e is None:
+                return None
+            if e.version != self._version(weight):
+                self._refresh()
+            cur = torch.cuda.current_stream(self.device)
+            if self.stream is not None and cur != self.stream and self.event is not None:
+                cur.wait_event(self.event)                       # packed on another stream
+            return e.panel
+
+    def _create(self, weight, d, direction, extras, weakref):
+        lib = _lib.load()
+        nb = c_size_t(0)
+        _lib.check(lib.zsv_conv3d_panel_query(byref(d), direction, extras, byref(nb)), "zsv_conv3d_panel_query")
+        if nb.value == 0:
+            return None
+        e = _Panel()
+        e.weight = weakref.ref(weight)
+        e.desc = ConvDesc(*d.key)
+        e.direction, e.extras = direction, extras
+        e.nbytes = int(nb.value)
+        e.panel = torch.empty(e.nbytes, dtype=torch.uint8, device=weight.device)
+        e.job = None
+        e.version = None
+        return e
+
+    def _record(self, e, w):
+        job = _lib.PackJob()
+        _lib.check(_lib.load().zsv_conv3d_panel_job(byref(e.desc), e.direction, e.extras, w.data_ptr(), e.panel.data_ptr(), e.nbytes,
+                                                   byref(job)), "zsv_conv3d_panel_job")
+        e.job = job
+        e.blocks = (int(job.total) + 1023) // 1024
+
+    def _refresh(self):
+        """Re-pack every panel whose weight changed, in one launch on the current stream."""
+        import ctypes
+        stale, dead = [], []
+        for key, e in self.entries.items():
+            if e is None:
+                continue
+            w = e.weight()
+            if w is None:
+                dead.append(key)
+                continue
+            v = self._version(w)
+            if e.version != v:
+                if e.job is None or e.job.w != w.data_ptr():
+                    self._record(e, w)                           # (first use, or the storage moved)
+                    self.table = None
+                stale.append((key, e, v))
+        for key in dead:
+            del self.entries[key]
+            self.table = None
+        if not stale:
+            return
+        keys = tuple(k for k, _, _ in stale)
+        if self.table is None or self.table[0] != keys:
+            first, raw = 0, bytearray()
+            for _, e, _ in stale:
+                e.job.first_block = first
+                first += e.blocks
+                raw += bytes(e.job)
+            host = torch.frombuffer(raw, dtype=torch.uint8)
+            self.table = (keys, host.to(self.device), first)      # (a blocking copy: only when the set of stale panels changes)
+        _, table, blocks = self.table
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().zsv_pack_multi(table.data_ptr(), len(stale), blocks, _stream()), "zsv_pack_multi")
+        self.stream = torch.cuda.current_stream(self.device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+        self.repacks += 1
+        for _, e, v in stale:
+            e.version = v
+
+
+_PANEL_CACHES = {}
+
+
+def _panel_for(weight, d, direction, extras):
+    if os.environ.get("ZSV_NO_PANEL_CACHE"):
+        return None
+    key = weight.device.index
+    cache = _PANEL_CACHES.get(key)
+    if cache is None:
+        cache = _PANEL_CACHES[key] = _PanelCache(weight.device)
+    return cache.get(weight, d, direction, 1 if extras else 0)
+
+
+def invalidate_panels():
+    """Forget every cached weight panel (after writing weights behind autograd's back without ``_lib.note_raw_write()``)."""
+    _PANEL_CACHES.clear()
+
+
 def conv_desc(x_shape: Sequence[int], w_shape: Sequence[int], stride, padding) -> ConvDesc:
     n, cin, ti, hi, wi = (int(v) for v in x_shape)
     cout, cin_w, kt, kh, kw = (int(v) for v in w_shape)
@@ -207,7 +344,9 @@ def conv_desc(x_shape: Sequence[int], w_shape: Sequence[int], stride, padding) -
     wo = (wi + 2 * pw - kw) // sw + 1
     if min(to, ho, wo) <= 0:
         raise RuntimeError(f"conv3d: kernel {(kt, kh, kw)} does not fit input {(ti, hi, wi)}")
-    return ConvDesc(n, cin, ti, hi, wi, cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
+    d = ConvDesc(n, cin, ti, hi, wi, cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
+    d.key = (n, cin, ti, hi, wi, cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)      # (hashable twin: panel cache)
+    return d
 
 
 class SkipLink:
@@ -266,9 +405,15 @@ class _Conv3d(Function):
                 if tiles > 0:
                     stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
             ev = timer.start() if (timer is not None and timer.wants("conv_fwd", d)) else None
-            _lib.check(lib.zsv_conv3d_fwd_stats(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
-                                                1 if relu else 0, _ptr(stats), tiles, _ptr(ws), nbytes, _stream()),
-                       "zsv_conv3d_fwd")
+            panel = _panel_for(weight, d, 0, bias is not None or relu or stats is not None)
+            if panel is None:
+                _lib.check(lib.zsv_conv3d_fwd_stats(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
+                                                    1 if relu else 0, _ptr(stats), tiles, _ptr(ws), nbytes, _stream()),
+                           "zsv_conv3d_fwd")
+            else:
+                _lib.check(lib.zsv_conv3d_fwd_full_panel(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), None, y.data_ptr(),
+                                                         1 if relu else 0, _ptr(stats), tiles, _ptr(ws), nbytes, _stream(),
+                                                         panel.data_ptr(), panel.numel()), "zsv_conv3d_fwd (panel)")
             if ev is not None:
                 timer.stop(ev)
         ctx.desc = d
@@ -324,8 +469,14 @@ class _Conv3d(Function):
                 dsub = torch.empty((d.N, d.Cin, d.To, d.Ho, d.Wo), dtype=torch.float32, device=dy.device)
                 nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d1))
                 ws = _workspace(nbytes, dy.device)
-                _lib.check(lib.zsv_conv3d_dgrad(byref(d1), dy.data_ptr(), weight.data_ptr(), dsub.data_ptr(), _ptr(ws), nbytes,
-                                                _stream()), "zsv_conv3d_dgrad (compact shortcut gradient)")
+                panel = _panel_for(weight, d1, 1, False)
+                if panel is None:
+                    _lib.check(lib.zsv_conv3d_dgrad(byref(d1), dy.data_ptr(), weight.data_ptr(), dsub.data_ptr(), _ptr(ws), nbytes,
+                                                    _stream()), "zsv_conv3d_dgrad (compact shortcut gradient)")
+                else:
+                    _lib.check(lib.zsv_conv3d_dgrad_add_panel(byref(d1), dy.data_ptr(), weight.data_ptr(), None, dsub.data_ptr(), _ptr(ws),
+                                                              nbytes, _stream(), panel.data_ptr(), panel.numel()),
+                               "zsv_conv3d_dgrad (compact shortcut gradient, panel)")
                 src.dsub = dsub
             elif ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
@@ -337,14 +488,25 @@ class _Conv3d(Function):
                 link = ctx.down_link
                 if link is not None:
                     link.consumed = True
+                panel = _panel_for(weight, d, 1, False)
+                pp, pn = (panel.data_ptr(), panel.numel()) if panel is not None else (None, 0)
                 if link is not None and link.dsub is not None:      # the strided shortcut's compact gradient
                     sub, link.dsub = link.dsub, None
-                    _lib.check(lib.zsv_conv3d_dgrad_add_strided(byref(d), dy.data_ptr(), weight.data_ptr(), sub.data_ptr(),
-                                                                link.strides[0], link.strides[1], link.strides[2], dx.data_ptr(),
-                                                                _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad_add_strided")
-                else:
+                    if panel is None:
+                        _lib.check(lib.zsv_conv3d_dgrad_add_strided(byref(d), dy.data_ptr(), weight.data_ptr(), sub.data_ptr(),
+                                                                    link.strides[0], link.strides[1], link.strides[2], dx.data_ptr(),
+                                                                    _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad_add_strided")
+                    else:
+                        _lib.check(lib.zsv_conv3d_dgrad_add_strided_panel(byref(d), dy.data_ptr(), weight.data_ptr(), sub.data_ptr(),
+                                                                          link.strides[0], link.strides[1], link.strides[2], dx.data_ptr(),
+                                                                          _ptr(ws), nbytes, _stream(), pp, pn),
+                                   "zsv_conv3d_dgrad_add_strided (panel)")
+                elif panel is None:
                     _lib.check(lib.zsv_conv3d_dgrad_add(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
                                                         _ptr(ws), nbytes, _stream()), "zsv_conv3d_dgrad")
+                else:
+                    _lib.check(lib.zsv_conv3d_dgrad_add_panel(byref(d), dy.data_ptr(), weight.data_ptr(), _ptr(add), dx.data_ptr(),
+                                                              _ptr(ws), nbytes, _stream(), pp, pn), "zsv_conv3d_dgrad (panel)")
             if ctx.needs_input_grad[1]:
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
 
@@ -427,7 +589,7 @@ class _BatchNormAct(Function):
                                                       float(momentum), float(eps), _ptr(stats), tiles, _ptr(ws), nbytes,
                                                       _stream()), "zsv_bn_fwd_train")
                 if running_mean is not None:
-                    _lib.note_raw_write()          # running statistics written behind the version counters
+                    _lib.note_raw_write(parameters=False)          # running statistics written behind the version counters
             else:
                 if running_mean is None or running_var is None:
                     raise RuntimeError("eval-mode BatchNorm needs running statistics")
@@ -518,7 +680,7 @@ class _BatchNormDeferred(Function):
                                                    float(momentum), float(eps), _ptr(stats), tiles, coef.data_ptr(), pitch,
                                                    _ptr(ws), nbytes, _stream()), "zsv_bn_fwd_train_coeffs")
         if running_mean is not None:
-            _lib.note_raw_write()
+            _lib.note_raw_write(parameters=False)
         ctx.dims = (n, c, s)
         ctx.save_for_backward(x, gamma, beta, save_mean, save_invstd)
         ctx.mark_non_differentiable(coef)
@@ -565,8 +727,14 @@ class _Conv3dPre(Function):
                 tiles = lib.zsv_conv3d_fwd_stat_tiles(byref(d), y.data_ptr())
                 if tiles > 0:
                     stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
-            _lib.check(lib.zsv_conv3d_fwd_pre(byref(d), x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), weight.data_ptr(),
-                                              y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd_pre")
+            panel = _panel_for(weight, d, 0, False)
+            if panel is None:
+                _lib.check(lib.zsv_conv3d_fwd_pre(byref(d), x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), weight.data_ptr(),
+                                                  y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd_pre")
+            else:
+                _lib.check(lib.zsv_conv3d_fwd_pre_panel(byref(d), x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), weight.data_ptr(),
+                                                        y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream(), panel.data_ptr(),
+                                                        panel.numel()), "zsv_conv3d_fwd_pre (panel)")
         ctx.desc = d
         ctx.save_for_backward(x, coef, weight)
         if stats is not None:
@@ -588,8 +756,13 @@ class _Conv3dPre(Function):
                 dx = torch.empty_like(x)
                 nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
                 ws = _workspace(nbytes, dy.device)
-                _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws), nbytes,
-                                                _stream()), "zsv_conv3d_dgrad")
+                panel = _panel_for(weight, d, 1, False)
+                if panel is None:
+                    _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws), nbytes,
+                                                    _stream()), "zsv_conv3d_dgrad")
+                else:
+                    _lib.check(lib.zsv_conv3d_dgrad_add_panel(byref(d), dy.data_ptr(), weight.data_ptr(), None, dx.data_ptr(), _ptr(ws),
+                                                              nbytes, _stream(), panel.data_ptr(), panel.numel()), "zsv_conv3d_dgrad (panel)")
             if ctx.needs_input_grad[2]:
                 nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(d))
                 pitch = int(coef.shape[1])
