@@ -64,6 +64,46 @@ __device__ __forceinline__ float pack_wino_value(const PackWinoArgs& a, const fl
     }
 }
 
+// all NP points of one (channel-in-block, row, row tap, channel block) triple: the three taps are read once (the per-element
+// formula above fetches them once per point) and the NP values go to NP panels, 16 consecutive channels = 64 contiguous bytes each.
+// `t` indexes the triples in the panel's own order with the point axis removed; values are pack_wino_value's, bit for bit.
+template <int NP>
+__device__ __forceinline__ void pack_wino_triple(const PackWinoArgs& a, const float* __restrict__ W, float* __restrict__ out, long t) {
+    const int c16 = (int)(t % 16);
+    long r = t / 16;
+    const int m = (int)(r % a.Mp);
+    r /= a.Mp;
+    const int kh = (int)(r % a.R);
+    const int cb = (int)(r / a.R);
+    const int c = cb * 16 + c16;
+    float* o = out + (((size_t)cb * a.R + kh) * NP * a.Mp + m) * 16 + c16;           // point 0; point pt is pt * Mp * 16 further
+    const size_t pstride = (size_t)a.Mp * 16;
+    if (!(m < a.M && c < a.C)) {
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) o[pt * pstride] = 0.f;
+        return;
+    }
+    const float* g = W + (size_t)m * a.sm + (size_t)c * a.sc;
+    const int last = 3 * a.R - 1;
+    const int k0 = a.flip ? last - (3 * kh + 0) : 3 * kh + 0, k1 = a.flip ? last - (3 * kh + 1) : 3 * kh + 1,
+              k2 = a.flip ? last - (3 * kh + 2) : 3 * kh + 2;
+    if constexpr (NP == 4) {
+        const float g0 = g[k0], g1 = g[k1], g2 = g[k2];
+        o[0] = g0;
+        o[pstride] = 0.5f * ((g0 + g2) + g1);
+        o[2 * pstride] = 0.5f * ((g0 + g2) - g1);
+        o[3 * pstride] = g2;
+    } else {
+        const double g0 = g[k0], g1 = g[k1], g2 = g[k2];
+        o[0] = (float)(g0 / 4);
+        o[pstride] = (float)(-((g0 + g2) + g1) / 6);
+        o[2 * pstride] = (float)(-((g0 + g2) - g1) / 6);
+        o[3 * pstride] = (float)((g0 / 24 + g2 / 6) + g1 / 12);
+        o[4 * pstride] = (float)((g0 / 24 + g2 / 6) - g1 / 12);
+        o[5 * pstride] = (float)g2;
+    }
+}
+
 // ---- kind 3: stride-2 input gradient (conv_dgrad_s2.hip): Wp[((chunk * NTAP + tap) * 8 + co % 8) * Mp + m] = W[co][m][tap] ----
 struct PackS2Args { int M, Mp, Cout, ntap; };
 __device__ __forceinline__ float pack_s2_value(const PackS2Args& a, const float* __restrict__ W, long i) {

@@ -29,9 +29,14 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const zsv_pack_job* __r
                                J.i[13], J.i[14], J.i[15], J.i[16], J.i[17], J.i[18]};
         for (long i = i0 + threadIdx.x; i < i1; i += 256) out[i] = pack_tap_value(a, W, i);
     } else if (J.kind == 1 || J.kind == 2) {
+        // per (channel, row, row tap) triple: three tap reads, NP stores (the job's blocks share its triples evenly)
         const PackWinoArgs a = {J.i[0], J.i[1], J.i[2], J.i[3], J.i[4], J.i[5], (long)J.l[0], (long)J.l[1]};
-        if (J.kind == 1) { for (long i = i0 + threadIdx.x; i < i1; i += 256) out[i] = pack_wino_value<4>(a, W, i); }
-        else { for (long i = i0 + threadIdx.x; i < i1; i += 256) out[i] = pack_wino_value<6>(a, W, i); }
+        const int np = J.kind == 1 ? 4 : 6;
+        const long triples = J.total / np, nblocks = (J.total + 1023) / 1024;
+        const long per = (triples + nblocks - 1) / nblocks;
+        const long t0 = (b - J.first_block) * per, t1 = t0 + per < triples ? t0 + per : triples;
+        if (J.kind == 1) { for (long t = t0 + threadIdx.x; t < t1; t += 256) pack_wino_triple<4>(a, W, out, t); }
+        else { for (long t = t0 + threadIdx.x; t < t1; t += 256) pack_wino_triple<6>(a, W, out, t); }
     } else {
         const PackS2Args a = {J.i[0], J.i[1], J.i[2], J.i[3]};
         for (long i = i0 + threadIdx.x; i < i1; i += 256) out[i] = pack_s2_value(a, W, i);
