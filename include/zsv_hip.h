@@ -131,32 +131,6 @@ int zsv_conv3d_fwd_pre(const zsv_conv_desc* d, const float* x, const float* pre_
                        void* stream);
 int zsv_conv3d_wgrad_pre(const zsv_conv_desc* d, const float* x, const float* pre_coef, int32_t coef_pitch,
                          const float* dy, float* dw, void* workspace, size_t workspace_bytes, void* stream);
-/* The backward of that BatchNorm (autograd's BatchNorm3d backward for resnet.py:48) needs two per-channel sums over the input
- * gradient g that the temporal convolution's zsv_conv3d_dgrad produces: sum g*mask and sum g*mask*xhat (mask = the ReLU's,
- * xhat = (x - mean) * invstd).  zsv_bn_bwd's first pass re-reads g and x for them (1.27 GB on layer1's mid tensor); the dgrad
- * kernel can add them up while it writes g, reading x alone:
- *   zsv_conv3d_dgrad_bnstat_tiles: partial sums per channel this geometry's dgrad writes (0 = no such epilogue: use
- *       zsv_conv3d_dgrad + zsv_bn_bwd).
- *   zsv_conv3d_dgrad_bnstats: zsv_conv3d_dgrad (same dx, bit for bit; `panel` as zsv_conv3d_dgrad_add_panel or NULL) that also
- *       writes bn->part = [2][Cin][tiles] floats.  bn->coef = [4][pitch]: scale, shift (zsv_bn_fwd_train_coeffs' coef rows)
- *       followed by a mean row and an invstd row (give zsv_bn_fwd_train_coeffs coef + 2*pitch / coef + 3*pitch as save_mean /
- *       save_invstd); bn->x = the BatchNorm's input (shape of dx).
- *   zsv_bn_bwd_from_stats: zsv_bn_bwd(fuse_relu = 2) minus its first pass: dgamma / dbeta / dx from those partials (summed in
- *       double, fixed order).  Agrees with zsv_bn_bwd to fp32 rounding of the sums (another summation order). */
-typedef struct zsv_bn_bwd_stats {
-    const float* x;
-    const float* coef;
-    int32_t pitch;
-    int32_t tiles;
-    float* part;
-} zsv_bn_bwd_stats;
-int32_t zsv_conv3d_dgrad_bnstat_tiles(const zsv_conv_desc* d);
-int zsv_conv3d_dgrad_bnstats(const zsv_conv_desc* d, const float* dy, const float* w, float* dx, const zsv_bn_bwd_stats* bn,
-                             void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes);
-int zsv_bn_bwd_from_stats(const float* g, const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
-                          const float* beta, const float* save_mean, const float* save_invstd, const float* part,
-                          int32_t tiles, float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
-                          void* stream);
 /* db[c] = sum over (n, s) of dy  (bias gradient of C3D's convs, network.py:102-117,
  * and of nn.Linear when S == 1). */
 size_t zsv_channel_sum_workspace_bytes(int32_t N, int32_t C, int32_t S);

@@ -829,20 +829,11 @@ def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, 
         return dict(y=y.detach(), stats=stats, dx=xg.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad, dw=conv.weight.grad,
                     rm=bn.running_mean.clone(), rv=bn.running_var.clone(), nbt=bn.num_batches_tracked.clone()), mask
 
-    # (the BatchNorm-backward sums from the dgrad epilogue are another summation order: second leg below)
-    monkeypatch.setenv("ZSV_NO_BN_BWD_FUSION", "1")
     (a, _), (b, mask) = run(True), run(False)
     for k in a:
         assert (a[k] is None) == (b[k] is None), k
         if a[k] is not None:
             assert torch.equal(a[k], b[k]), f"fused vs unfused differ in {k}"
-    monkeypatch.delenv("ZSV_NO_BN_BWD_FUSION")
-    a2, _ = run(True)
-    for k in ("y", "stats", "dw", "rm", "rv", "nbt"):
-        if a[k] is not None:
-            assert torch.equal(a2[k], a[k]), f"the backward-sum epilogue changed {k}"
-    for k in ("dx", "dgamma", "dbeta"):
-        close(a2[k], a[k], rtol=2e-5, what=f"{k} with the sums from the dgrad epilogue")
     xr = x.double().requires_grad_()
     gr, br, wr = gamma.double().requires_grad_(), beta.double().requires_grad_(), wt.double().requires_grad_()
     # (the reference uses the device's own ReLU mask: a pre-activation within rounding of 0 may differ in sign)
@@ -1376,82 +1367,3 @@ def test_weight_panels_packed_ahead_of_the_call(case):
     nb = ctypes.c_size_t(1)
     _lib.check(lib.zsv_conv3d_panel_query(ctypes.byref(ds), 0, 0, ctypes.byref(nb)), "query stem")
     assert nb.value == 0
-
-
-BNSTAT_CASES = [
-    # name, mid-tensor shape (N, C, T, H, W), output channels of the temporal convolution
-    ("layer1_like", (3, 144, 16, 12, 12), 64),
-    ("ragged_rows_t8", (2, 230, 8, 14, 14), 128),        # 230 channels: the last 48-row tile is ragged
-    ("t4_tail", (5, 70, 4, 7, 12), 40),                  # 84 positions per frame: the second 64-position segment is mostly empty
-]
-
-
-@pytest.mark.parametrize("case", BNSTAT_CASES, ids=[c[0] for c in BNSTAT_CASES])
-def test_dgrad_epilogue_batchnorm_backward_sums(case, monkeypatch):
-    """C ABI: zsv_conv3d_dgrad_bnstats / zsv_bn_bwd_from_stats.  The temporal input-gradient kernel that also adds up the
-    BatchNorm-backward sums of the BatchNorm in front of its convolution writes the SAME dx as zsv_conv3d_dgrad, and
-    zsv_bn_bwd_from_stats on its partials gives zsv_bn_bwd(fuse_relu = 2)'s dx / dgamma / dbeta to fp32 rounding of the sums."""
-    import ctypes
-    from zeroshotvideoclassification_amd import _lib
-    name, xs, cout = case
-    monkeypatch.setenv("ZSV_WINOT_MIN_TILES", "1")                             # (small problems: below the planner's limits)
-    monkeypatch.setenv("ZSV_WINOT_MAX_WASTE", "100")
-    lib = _lib.load()
-    n, c, t, h, w_ = xs
-    s = t * h * w_
-    g = torch.Generator().manual_seed(len(name))
-    x = (torch.randn(*xs, generator=g) * 1.5 + 0.3).to(DEV)                    # the BatchNorm's input (the spatial convolution's output)
-    gamma = (torch.rand(c, generator=g) + 0.5).to(DEV)
-    beta = (torch.randn(c, generator=g) * 0.3).to(DEV)
-    wt = (torch.randn(cout, c, 3, 1, 1, generator=g) / np.sqrt(3 * c)).to(DEV)
-    d = ops.conv_desc(xs, wt.shape, 1, (1, 0, 0))
-    dy = torch.randn(n, cout, t, h, w_, generator=g).to(DEV)
-    tiles = lib.zsv_conv3d_dgrad_bnstat_tiles(ctypes.byref(d))
-    assert tiles > 0, name
-    pitch = (c + 15) // 16 * 16
-    coef = torch.zeros((4, pitch), device=DEV)
-    nb = lib.zsv_bn_workspace_bytes(n, c, s)
-    bws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=DEV)
-    _lib.check(lib.zsv_bn_fwd_train_coeffs(x.data_ptr(), n, c, s, gamma.data_ptr(), beta.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
-                                           None, None, 0.1, 1e-5, None, 0, coef.data_ptr(), pitch, bws.data_ptr(), nb, None), "coeffs")
-    nd = lib.zsv_conv3d_dgrad_workspace_bytes(ctypes.byref(d))
-    ws = torch.empty(max(int(nd), 16), dtype=torch.uint8, device=DEV)
-    dx_ref, dx = torch.empty(xs, device=DEV), torch.empty(xs, device=DEV)
-    _lib.check(lib.zsv_conv3d_dgrad(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx_ref.data_ptr(), ws.data_ptr(), nd, None), "dgrad")
-    part = torch.full((2, c, tiles), float("nan"), device=DEV)
-    bn = _lib.BnBwdStats(x.data_ptr(), coef.data_ptr(), pitch, tiles, part.data_ptr())
-    _lib.check(lib.zsv_conv3d_dgrad_bnstats(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctypes.byref(bn), ws.data_ptr(), nd, None,
-                                            None, 0), "dgrad_bnstats")
-    torch.cuda.synchronize()
-    assert torch.equal(dx, dx_ref), name
-    assert torch.isfinite(part).all()
-    # the sums against a double-precision restatement
-    xd, gd = x.double(), dx_ref.double()
-    mean, invstd = coef[2, :c].double().view(1, c, 1, 1, 1), coef[3, :c].double().view(1, c, 1, 1, 1)
-    xhat = (xd - mean) * invstd
-    mask = (xhat * gamma.double().view(1, c, 1, 1, 1) + beta.double().view(1, c, 1, 1, 1)) > 0
-    gm = gd * mask
-    close(part[0].double().sum(1), gm.sum((0, 2, 3, 4)), rtol=1e-4, what="sum g*mask")
-    close(part[1].double().sum(1), (gm * xhat).sum((0, 2, 3, 4)), rtol=1e-4, what="sum g*mask*xhat")
-    # the BatchNorm backward from the partials against the three-pass one
-    outs = []
-    for fused in (False, True):
-        bdx, dgamma, dbeta = torch.empty(xs, device=DEV), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-        if fused:
-            _lib.check(lib.zsv_bn_bwd_from_stats(dx.data_ptr(), x.data_ptr(), n, c, s, gamma.data_ptr(), beta.data_ptr(), coef[2].data_ptr(),
-                                                 coef[3].data_ptr(), part.data_ptr(), tiles, bdx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                 bws.data_ptr(), nb, None), "bn_bwd_from_stats")
-        else:
-            _lib.check(lib.zsv_bn_bwd(dx.data_ptr(), x.data_ptr(), None, n, c, s, gamma.data_ptr(), beta.data_ptr(), coef[2].data_ptr(),
-                                      coef[3].data_ptr(), 2, bdx.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(), bws.data_ptr(), nb, None),
-                       "bn_bwd")
-        torch.cuda.synchronize()
-        outs.append((bdx, dgamma, dbeta))
-    for a, b, what in zip(outs[1], outs[0], ("dx", "dgamma", "dbeta")):
-        close(a, b, rtol=2e-5, what=what)
-    # a panel packed ahead works the same way; wrong tile counts and other geometries are refused
-    bn_bad = _lib.BnBwdStats(x.data_ptr(), coef.data_ptr(), pitch, tiles + 1, part.data_ptr())
-    assert lib.zsv_conv3d_dgrad_bnstats(ctypes.byref(d), dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctypes.byref(bn_bad), ws.data_ptr(), nd, None,
-                                        None, 0) != 0
-    dsp = ops.conv_desc((2, 64, 4, 24, 24), (144, 64, 1, 3, 3), 1, (0, 1, 1))
-    assert lib.zsv_conv3d_dgrad_bnstat_tiles(ctypes.byref(dsp)) == 0

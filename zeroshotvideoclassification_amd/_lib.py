@@ -96,9 +96,6 @@ SIGNATURES = {
     "zsv_conv3d_dgrad_add_panel": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t, _P, _P, c_size_t]),
     "zsv_conv3d_dgrad_add_strided_panel": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P, _P,
                                                    c_size_t]),
-    "zsv_conv3d_dgrad_bnstat_tiles": (c_int32, [POINTER(ConvDesc)]),
-    "zsv_conv3d_dgrad_bnstats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_size_t, _P, _P, c_size_t]),
-    "zsv_bn_bwd_from_stats": (c_int, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 
@@ -106,12 +103,6 @@ class PackJob(Structure):
     """Mirror of ``zsv_pack_job`` (include/zsv_hip.h): one weight-panel pack launch written down for ``zsv_pack_multi``."""
     _fields_ = [("kind", c_int32), ("reserved", c_int32), ("total", c_int64), ("first_block", c_int64), ("w", c_void_p),
                 ("out", c_void_p), ("l", c_int64 * 2), ("i", c_int32 * 20)]
-
-
-class BnBwdStats(Structure):
-    """Mirror of ``zsv_bn_bwd_stats`` (include/zsv_hip.h): what ``zsv_conv3d_dgrad_bnstats`` needs of the BatchNorm in front."""
-    _fields_ = [("x", c_void_p), ("coef", c_void_p), ("pitch", c_int32), ("tiles", c_int32), ("part", c_void_p)]
-
 
 _lock = threading.Lock()
 _lib = None

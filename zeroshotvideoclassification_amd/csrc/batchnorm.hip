@@ -301,8 +301,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // dgamma = sum g*xhat, dbeta = sum g;  dx = a*g + b*x + k  with
 //   a = gamma*invstd, b = -a*invstd*dgamma/M, k = -a*dbeta/M - b*mean
-template <typename PT>
-__global__ void bn_bwd_finalize_kernel(const PT* __restrict__ part, int C, int slices, double count,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int slices, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
@@ -311,22 +310,14 @@ __global__ void bn_bwd_finalize_kernel(const PT* __restrict__ part, int C, int s
     // one 64-lane wave per channel: lane l adds slices l, l + 64, ... in order, then the lanes are combined by xor-shuffles -- a
     // fixed order (bitwise reproducible); a single thread walking up to ~35 slices with dependent adds took 16 us per launch,
     // 37 launches per step on the backward's critical path
-    // (blockDim 64, or 256 for the thousands of per-tile partials of a convolution epilogue: waves combined through LDS in order)
     const int c = blockIdx.x;
     double sg = 0.0, sgx = 0.0;
-    for (int k = threadIdx.x; k < slices; k += blockDim.x) {
-        sg += (double)part[(size_t)c * slices + k];
-        sgx += (double)part[(size_t)(C + c) * slices + k];
+    for (int k = threadIdx.x; k < slices; k += 64) {
+        sg += part[(size_t)c * slices + k];
+        sgx += part[(size_t)(C + c) * slices + k];
     }
     sg = wave_sum(sg);
     sgx = wave_sum(sgx);
-    if (blockDim.x > 64) {
-        __shared__ double wsum[2][4];
-        if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = sg; wsum[1][threadIdx.x >> 6] = sgx; }
-        __syncthreads();
-        sg = (wsum[0][0] + wsum[0][1]) + (wsum[0][2] + wsum[0][3]);
-        sgx = (wsum[1][0] + wsum[1][1]) + (wsum[1][2] + wsum[1][3]);
-    }
     if (threadIdx.x != 0) return;
     if (dgamma) dgamma[c] = (float)sgx;
     if (dbeta) dbeta[c] = (float)sg;
@@ -549,7 +540,7 @@ extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
     if ((st = launch_status())) return st;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(C), dim3(64), 0, stream, (const double*)w.part, C, slices,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C, slices,
                        (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
     if ((st = launch_status())) return st;
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
@@ -558,27 +549,5 @@ extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32
     else if (fuse_relu == 1) { if (d_residual) ZSV_BWD_APPLY(1, true); else ZSV_BWD_APPLY(1, false); }
     else { if (d_residual) ZSV_BWD_APPLY(0, true); else ZSV_BWD_APPLY(0, false); }
 #undef ZSV_BWD_APPLY
-    return launch_status();
-}
-
-// zsv_bn_bwd(fuse_relu = 2) without its reduction pass: the sums come as per-tile partials from the epilogue of the input-gradient
-// kernel that produced g (zsv_conv3d_dgrad_bnstats)
-extern "C" int zsv_bn_bwd_from_stats(const float* g, const float* x, int32_t N, int32_t C, int32_t S, const float* gamma,
-                                     const float* beta, const float* save_mean, const float* save_invstd, const float* part,
-                                     int32_t tiles, float* dx, float* dgamma, float* dbeta, void* workspace,
-                                     size_t workspace_bytes, void* stream_) {
-    int st = check_ncs(N, C, S);
-    if (st) return st;
-    if (!g || !x || !dx || !save_mean || !save_invstd || !part || !workspace) return ZSV_E_NULL;
-    if (tiles <= 0) return ZSV_E_BAD_SHAPE;
-    if (workspace_bytes < bn_ws_bytes(N, C, S)) return ZSV_E_WORKSPACE;
-    hipStream_t stream = (hipStream_t)stream_;
-    BnWs w = bn_ws(workspace, C, bn_slices(N, C, S));
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(C), dim3(tiles > 512 ? 256 : 64), 0, stream, part, C, tiles, (double)N * S, gamma, save_mean,
-                       save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
-    if ((st = launch_status())) return st;
-    const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<2, false>), grid, dim3(256), 0, stream, g, x, (const float*)nullptr, dx, (float*)nullptr, C, S,
-                       w.scale, w.shift, w.c1, gamma, save_invstd, w.c2);
     return launch_status();
 }

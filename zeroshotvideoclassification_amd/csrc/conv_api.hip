@@ -469,20 +469,3 @@ extern "C" int zsv_conv3d_dgrad_add_strided_panel(const zsv_conv_desc* d, const 
     PanelScope scope(PANEL_LAUNCH_ONLY, const_cast<void*>(panel), panel_bytes);
     return zsv_conv3d_dgrad_add_strided(d, dy, w, sub, st, sh, sw, dx, workspace, workspace_bytes, stream);
 }
-
-// ---- input gradient with the BatchNorm-backward sums of the BatchNorm in front of the convolution (zsv_hip.h) -------------------
-extern "C" int32_t zsv_conv3d_dgrad_bnstat_tiles(const zsv_conv_desc* d) {
-    if (conv_check(d) != ZSV_OK || !wino_dgrad_applicable(d)) return 0;
-    return wino_dgrad_bnstat_tiles(d);
-}
-
-extern "C" int zsv_conv3d_dgrad_bnstats(const zsv_conv_desc* d, const float* dy, const float* w, float* dx, const zsv_bn_bwd_stats* bn,
-                                        void* workspace, size_t workspace_bytes, void* stream, const void* panel, size_t panel_bytes) {
-    int st = conv_check(d);
-    if (st) return st;
-    if (!dy || !w || !dx || !bn || !bn->x || !bn->coef || !bn->part) return ZSV_E_NULL;
-    if (bn->tiles <= 0 || bn->tiles != zsv_conv3d_dgrad_bnstat_tiles(d)) return ZSV_E_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(bn->coef) & 3) || (reinterpret_cast<uintptr_t>(bn->x) & 3)) return ZSV_E_BAD_SHAPE;
-    PanelScope scope(panel ? PANEL_LAUNCH_ONLY : PANEL_NONE, const_cast<void*>(panel), panel_bytes);
-    return wino_dgrad(d, dy, w, nullptr, dx, workspace, workspace_bytes, (hipStream_t)stream, bn);
-}

@@ -241,8 +241,7 @@ int wgrad_generic(const zsv_conv_desc* d, const float* x, const float* dy, float
 bool wino_dgrad_applicable(const zsv_conv_desc* d);
 size_t wino_dgrad_workspace_bytes(const zsv_conv_desc* d);
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
-               size_t workspace_bytes, hipStream_t stream, const zsv_bn_bwd_stats* bn = nullptr);
-int wino_dgrad_bnstat_tiles(const zsv_conv_desc* d);      // partial BatchNorm-backward sums per channel from the dgrad epilogue (0: none)
+               size_t workspace_bytes, hipStream_t stream);
 // every residue class of a stride-2 dgrad in one launch (conv_dgrad_s2.hip): 1x3x3 stride (1,2,2) and 3x1x1 stride (2,1,1)
 bool dgrad_s2_applicable(const zsv_conv_desc* d);
 size_t dgrad_s2_workspace_bytes(const zsv_conv_desc* d);

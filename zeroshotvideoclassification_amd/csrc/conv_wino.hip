@@ -61,11 +61,6 @@ struct WinoParams {
     unsigned out_bytes;     // bytes of the produced tensor (buffer-addressed stores of the temporal F(4,3) kernel)
     const float* pre_coef;
     int pre_pitch;
-    // temporal F(4,3) dgrad with the BatchNorm-backward sums of the BatchNorm in front of the convolution (EPI 3): bn_x = that
-    // BatchNorm's input (shape of OUT), bn_coef = [4][bn_pitch] scale, shift, mean, invstd; the sums go to stat_sum / stat_sq
-    const float* bn_x;
-    const float* bn_coef;
-    int bn_pitch;
 };
 
 // Up[(cb*R + r)*4 + pt][Mp][c%16] from G[m][c][r][kw] = W[m*sm + c*sc + (flip ? 3R-1 - (3*r+kw) : 3*r+kw)], r = kt*3 + kh
@@ -965,10 +960,7 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
 // QUADS per workgroup, one 16-quad block (16 positions of one quad) per wave, six accumulator sets.  At 64 rows the six U panels are
 // single-buffered (a second barrier per chunk, as conv_wino4_kernel) so that two workgroups fit a CU.
 // EPI selects the epilogue at compile time: 0 = plain stores (the input gradients), 1 = + BatchNorm partial statistics (the
-// training forward), 2 = run-time add / bias / ReLU (+ statistics) (inference engine, shortcut gradients), 3 = plain stores + the
-// BatchNorm-BACKWARD sums of the BatchNorm whose (virtual) output this input gradient belongs to: sum g*mask and sum g*mask*xhat per
-// row, mask / xhat recomputed from that BatchNorm's input x exactly as bn_bwd_reduce_kernel<2> does -- its two reads of a 636 MB
-// tensor become one read of x here, under the other workgroup's MFMAs.  With K = 64 .. 144
+// training forward), 2 = run-time add / bias / ReLU (+ statistics) (inference engine, shortcut gradients).  With K = 64 .. 144
 // channels these kernels run 4 - 9 chunks per tile, so what surrounds the chunk loop counts: the run-time-flag epilogue compiled to
 // ~130 instructions and five branches per output row (1 480 vector instructions per wave against 288 MFMAs on the layer1 dgrad,
 // profiles/r03_t1_pmc.json); EPI 0 / 1 are branch-free: buffer stores whose row / frame offsets are scalar, out-of-range lanes
@@ -1056,26 +1048,6 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
 
     issue(0, 0);
-    // EPI 3 at 48 rows: this lane's 48 values of the BatchNorm input x are requested HERE and sit in registers through the chunk
-    // loop (192 + 48 VGPRs) -- the loop is 4 - 9 chunks long, a load round trip exposed in the epilogue costs as much as two of them
-    // (T1 dgrad: + 17 % with the loads in the epilogue).  64-row tiles have no registers to spare and load in the epilogue.
-    constexpr bool XPRE = EPI == 3 && TM == 3;
-    [[maybe_unused]] float xpre[XPRE ? TM : 1][4][4];
-    if constexpr (XPRE) {
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prm.bn_x), 0, prm.out_bytes, 0x00020000);
-        const int posx = pos0 + col;
-        const bool okx = posx < HW;
-        const unsigned lane_off = okx ? 4u * (unsigned)(n_img * prm.M * prm.S + 4 * tq * HW + posx + (m0 + 4 * g) * prm.S) : 0xFFFFFFFFu;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned voff = (okx && m0 + 16 * i + 4 * g + r < prm.M) ? lane_off : 0xFFFFFFFFu;
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    xpre[i][r][f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, (int)voff, (16 * i + r) * 4 * prm.S + f * 4 * HW, 0));
-            }
-    }
     __syncthreads();                                   // (vmcnt(0) before the barrier)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
@@ -1154,34 +1126,9 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
         const unsigned lane_off = ok ? 4u * (unsigned)(n_img * prm.M * prm.S + 4 * tq * HW + pos + (m0 + 4 * g) * prm.S) : OOB;
         const bool ragged = m0 + BM > prm.M;                  // (wave-uniform)
         const int row_bytes = 4 * prm.S, frame_bytes = 4 * HW;
-        if (EPI == 1 || EPI == 3) __syncthreads();
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t xrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == 3 ? prm.bn_x : IN), 0, EPI == 3 ? prm.out_bytes : 0u, 0x00020000);
-        [[maybe_unused]] const __amdgpu_buffer_rsrc_t crsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == 3 ? prm.bn_coef : IN), 0, EPI == 3 ? 16u * (unsigned)prm.bn_pitch : 0u, 0x00020000);
-        [[maybe_unused]] const int coef_row = 4 * prm.bn_pitch;
+        if (EPI == 1) __syncthreads();
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            // EPI 3: the four rows' x values and coefficients are requested before the first store of the block
-            [[maybe_unused]] float xv[4][4], csc[4], csh[4], cmu[4], cis[4];
-            if constexpr (EPI == 3) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool live = ok && (!ragged || m0 + 16 * i + 4 * g + r < prm.M);
-                    const unsigned voff = live ? lane_off : OOB;
-                    const unsigned coff = live ? 4u * (unsigned)(m0 + 16 * i + 4 * g + r) : OOB;
-                    const int soff = (16 * i + r) * row_bytes;
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        if constexpr (XPRE) xv[r][f] = xpre[i][r][f];
-                        else xv[r][f] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)voff, soff + f * frame_bytes, 0));
-                    }
-                    csc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, (int)coff, 0, 0));
-                    csh[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, (int)coff, coef_row, 0));
-                    cmu[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, (int)coff, 2 * coef_row, 0));
-                    cis[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(crsrc, (int)coff, 3 * coef_row, 0));
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float M0 = acc[0][i][r], M1 = acc[1][i][r], M2 = acc[2][i][r], M3 = acc[3][i][r], M4 = acc[4][i][r], M5 = acc[5][i][r];
@@ -1196,21 +1143,9 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
                 const int soff = (16 * i + r) * row_bytes;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[f]), orsrc, (int)voff, soff + f * frame_bytes, 0);
-                if constexpr (EPI == 1 || EPI == 3) {
-                    float s1, s2;
-                    if constexpr (EPI == 1) {
-                        s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
-                        s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
-                    } else {
-                        float gm[4], xh[4];
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) {          // (the mask and xhat of bn_bwd_reduce_kernel<2>)
-                            gm[f] = (live && __fmaf_rn(xv[r][f], csc[r], csh[r]) > 0.f) ? y[f] : 0.f;
-                            xh[f] = (xv[r][f] - cmu[r]) * cis[r];
-                        }
-                        s1 = (gm[0] + gm[1]) + (gm[2] + gm[3]);
-                        s2 = (gm[0] * xh[0] + gm[1] * xh[1]) + (gm[2] * xh[2] + gm[3] * xh[3]);
-                    }
+                if constexpr (EPI == 1) {
+                    float s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
+                    float s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
                     // the 16 lanes of a DPP row share output row m: quad swaps, then the two mirrors
 #define ZSV_ROW16_SUM(v)                                                                                                         \
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));                               \
@@ -1264,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
         }
     }
     }
-    if (EPI == 1 || EPI == 3 || (EPI == 2 && prm.stat_sum != nullptr)) {
+    if (EPI == 1 || (EPI == 2 && prm.stat_sum != nullptr)) {
         __syncthreads();
         if (tid < BM && m0 + tid < prm.M) {
             const float t1 = (red[tid * 2] + red[(BM + tid) * 2]) + (red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2]);
@@ -1463,9 +1398,6 @@ static int winot4_launch_epi(const WinoParams& p, const float* up, const float* 
 }
 template <int TM, bool PRE>
 static int winot4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
-    if constexpr (!PRE) {
-        if (p.bn_x != nullptr) return winot4_launch_epi<TM, PRE, 3>(p, up, in, out, stream);
-    }
     if (p.add != nullptr || p.bias != nullptr || p.relu || ZSV_KNOB(WINOT_GENERIC_EPILOGUE)) return winot4_launch_epi<TM, PRE, 2>(p, up, in, out, stream);
     return p.stat_sum != nullptr ? winot4_launch_epi<TM, PRE, 1>(p, up, in, out, stream) : winot4_launch_epi<TM, PRE, 0>(p, up, in, out, stream);
 }
@@ -1474,7 +1406,7 @@ static int winot4_launch(const WinoParams& p, const float* up, const float* in, 
 static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, const float* w, long sm, long sc, int flip,
                      const float* add, const float* bias, int relu, float* stat_sum, float* stat_sq, const float* pre_coef,
                      int pre_pitch, float* out,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream, const zsv_bn_bwd_stats* bn = nullptr) {
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!workspace || workspace_bytes < wino_bytes(d, M, C)) return ZSV_E_WORKSPACE;
     const int tm = wino_tm(M), bm = 16 * tm;
     WinoParams p;
@@ -1495,16 +1427,10 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.add = add; p.bias = bias; p.relu = relu; p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.ksplit = 1; p.chunks_per_split = p.nblk; p.slab_elems = 0;
     p.pre_coef = pre_coef; p.pre_pitch = pre_pitch;
-    p.bn_x = nullptr; p.bn_coef = nullptr; p.bn_pitch = 0;
-    const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
-    if (bn) {
-        if (!f43 || add || bias || relu || stat_sum || pre_coef || bn->tiles != p.tiles_n || bn->pitch < M) return ZSV_E_UNSUPPORTED;
-        p.bn_x = bn->x; p.bn_coef = bn->coef; p.bn_pitch = bn->pitch;
-        p.stat_sum = bn->part; p.stat_sq = bn->part + (size_t)M * p.tiles_n;
-    }
     float* up;
     int pst;
     if (!panel_place(wino_bytes(d, M, C), workspace, up, pst)) return pst;
+    const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
     const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
     if (g_panel.mode == PANEL_RECORD) {
         pack_job_wino(g_panel.job, f43 ? 6 : 4, PackWinoArgs{p.M, p.Mp, p.C, p.nblk, 1, flip, sm, sc}, w, up, total);
@@ -1596,17 +1522,11 @@ static int wino_run(const zsv_conv_desc* d, int M, int C, const float* in, const
     return splitk_reduce(slabs, ks, p.slab_elems, M, p.S, bias, relu, final_out, stream);
 }
 
-int wino_dgrad_bnstat_tiles(const zsv_conv_desc* d) {
-    if (!winot_geometry(d, d->Cin) || ZSV_KNOB(WINOT_NO_F43) || ZSV_KNOB(WINOT_GENERIC_EPILOGUE)) return 0;
-    return d->N * winot_segs(d);
-}
-
 int wino_dgrad(const zsv_conv_desc* d, const float* dy, const float* w, const float* add, float* dx, void* workspace,
-               size_t workspace_bytes, hipStream_t stream, const zsv_bn_bwd_stats* bn) {
+               size_t workspace_bytes, hipStream_t stream) {
     if (winot_geometry(d, d->Cin))          // G[m = ci][c = co][kt] = W[co][ci][2 - kt]
         return winot_run(d, d->Cin, d->Cout, dy, w, 3, (long)d->Cin * 3, 1, add, nullptr, 0, nullptr, nullptr, nullptr, 0, dx, workspace,
-                         workspace_bytes, stream, bn);
-    if (bn) return ZSV_E_UNSUPPORTED;
+                         workspace_bytes, stream);
     // G[m = ci][c = co][kt][kh][kw] = W[co][ci][kT-1-kt][2-kh][2-kw]: stride of m is 9*kT, of c is Cin*9*kT, taps flipped
     const long taps = 9L * d->kT;
     return wino_run(d, d->Cin, d->Cout, dy, w, taps, (long)d->Cin * taps, 1, add, nullptr, 0, nullptr, nullptr, dx, workspace,

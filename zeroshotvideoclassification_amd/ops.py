@@ -656,7 +656,7 @@ class _BatchNormDeferred(Function):
     activation, which is exactly what this backward expects (``zsv_bn_bwd`` with the ReLU mask recomputed from x)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, stats, link=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, stats):
         _require(x, gamma, beta, running_mean, running_var, stats)
         if not x.is_contiguous():
             raise RuntimeError("deferred BatchNorm needs a contiguous input")
@@ -664,12 +664,9 @@ class _BatchNormDeferred(Function):
         s = x.numel() // (n * c)
         lib = _lib.load()
         pitch = (c + 15) // 16 * 16
-        # rows: scale, shift (what the consuming convolution applies), mean, invstd (what its input-gradient epilogue needs next to
-        # them for the BatchNorm-backward sums: zsv_bn_bwd_stats)
-        coef = torch.empty((4, pitch), dtype=torch.float32, device=x.device)
-        save_mean = coef[2, :c]
-        save_invstd = coef[3, :c]
-        ctx.link = link
+        coef = torch.empty((2, pitch), dtype=torch.float32, device=x.device)
+        save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty(c, dtype=torch.float32, device=x.device)
         tiles = 0
         if stats is not None:
             if stats.dim() != 3 or stats.shape[0] != 2 or stats.shape[1] != c or not stats.is_contiguous():
@@ -701,26 +698,12 @@ class _BatchNormDeferred(Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
         nbytes = lib.zsv_bn_workspace_bytes(n, c, s)
         ws = _workspace(nbytes, x.device)
-        link = ctx.link
-        part = None
-        if link is not None and link.part is not None:
-            # the sums of the first pass came out of the epilogue of the kernel that wrote g -- valid only if g IS that tensor,
-            # untouched (autograd adds a second consumer's gradient in place: the version counter tells)
-            if g.data_ptr() == link.dx_ptr and g._version == link.dx_version:
-                part = link.part
-            link.part = None
         with torch.cuda.device(x.device):
-            if part is not None:
-                _lib.check(lib.zsv_bn_bwd_from_stats(g.data_ptr(), x.data_ptr(), n, c, s, _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
-                                                     save_invstd.data_ptr(), part.data_ptr(), int(part.shape[2]), dx.data_ptr(),
-                                                     dgamma.data_ptr(), dbeta.data_ptr(), _ptr(ws), nbytes, _stream()),
-                           "zsv_bn_bwd_from_stats")
-            else:
-                _lib.check(lib.zsv_bn_bwd(g.data_ptr(), x.data_ptr(), None, n, c, s, _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
-                                          save_invstd.data_ptr(), 2, dx.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(),
-                                          _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
+            _lib.check(lib.zsv_bn_bwd(g.data_ptr(), x.data_ptr(), None, n, c, s, _ptr(gamma), _ptr(beta), save_mean.data_ptr(),
+                                      save_invstd.data_ptr(), 2, dx.data_ptr(), None, dgamma.data_ptr(), dbeta.data_ptr(),
+                                      _ptr(ws), nbytes, _stream()), "zsv_bn_bwd")
         return (dx if ctx.needs_input_grad[0] else None, dgamma if ctx.needs_input_grad[1] else None,
-                dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None, None)
+                dbeta if ctx.needs_input_grad[2] else None, None, None, None, None, None)
 
 
 class _Conv3dPre(Function):
@@ -728,7 +711,7 @@ class _Conv3dPre(Function):
     PRE form; weight gradient: the frame-ring kernel's PRE form)."""
 
     @staticmethod
-    def forward(ctx, x, coef, weight, stride, padding, want_stats, link=None):
+    def forward(ctx, x, coef, weight, stride, padding, want_stats):
         _require(x, coef, weight)
         weight = weight.contiguous()
         d = conv_desc(x.shape, weight.shape, stride, padding)
@@ -753,7 +736,6 @@ class _Conv3dPre(Function):
                                                         y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream(), panel.data_ptr(),
                                                         panel.numel()), "zsv_conv3d_fwd_pre (panel)")
         ctx.desc = d
-        ctx.link = link if (link is not None and coef.shape[0] == 4) else None
         ctx.save_for_backward(x, coef, weight)
         if stats is not None:
             ctx.mark_non_differentiable(stats)
@@ -766,7 +748,7 @@ class _Conv3dPre(Function):
         d = ctx.desc
         lib = _lib.load()
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None
         dy = dy.contiguous()
         dx = dw = None
         with torch.cuda.device(dy.device):
@@ -775,21 +757,7 @@ class _Conv3dPre(Function):
                 nbytes = lib.zsv_conv3d_dgrad_workspace_bytes(byref(d))
                 ws = _workspace(nbytes, dy.device)
                 panel = _panel_for(weight, d, 1, False)
-                link = ctx.link
-                tiles = 0
-                if link is not None:
-                    link.part = None
-                    if not os.environ.get("ZSV_NO_BN_BWD_FUSION"):
-                        tiles = int(lib.zsv_conv3d_dgrad_bnstat_tiles(byref(d)))
-                if tiles > 0:
-                    # the BatchNorm in front of this convolution gets its backward sums from this kernel's epilogue
-                    part = torch.empty((2, d.Cin, tiles), dtype=torch.float32, device=dy.device)
-                    bn = _lib.BnBwdStats(x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), tiles, part.data_ptr())
-                    _lib.check(lib.zsv_conv3d_dgrad_bnstats(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), byref(bn), _ptr(ws),
-                                                            nbytes, _stream(), _ptr(panel), panel.numel() if panel is not None else 0),
-                               "zsv_conv3d_dgrad_bnstats")
-                    link.part, link.dx_ptr, link.dx_version = part, dx.data_ptr(), dx._version
-                elif panel is None:
+                if panel is None:
                     _lib.check(lib.zsv_conv3d_dgrad(byref(d), dy.data_ptr(), weight.data_ptr(), dx.data_ptr(), _ptr(ws), nbytes,
                                                     _stream()), "zsv_conv3d_dgrad")
                 else:
@@ -807,7 +775,7 @@ class _Conv3dPre(Function):
                     return out
 
                 dw = _on_wgrad_stream(launch, (x, coef, dy), weight)
-        return dx, None, dw, None, None, None, None
+        return dx, None, dw, None, None, None
 
 
 def conv_pre_supported(x_shape, weight_shape, stride, padding) -> bool:
@@ -827,27 +795,11 @@ def bn_module_deferred(x, bn: torch.nn.Module, stats=None):
             bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    link = BnBwdLink()
-    handle, coef = _BatchNormDeferred.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), stats, link)
-    coef._zsv_bn_link = link          # (picked up by conv3d_pre: the consumer's input-gradient kernel fills it in the backward)
-    return handle, coef
-
-
-class BnBwdLink:
-    """Between a deferred BatchNorm and the convolution that consumes it: in the backward the convolution's input-gradient kernel
-    adds up the BatchNorm-backward sums while it writes its result (``zsv_conv3d_dgrad_bnstats``) and leaves them here; the
-    BatchNorm's backward then skips its own reduction pass over that tensor (``zsv_bn_bwd_from_stats``)."""
-    __slots__ = ("part", "dx_ptr", "dx_version")
-
-    def __init__(self):
-        self.part = None
-        self.dx_ptr = 0
-        self.dx_version = -1
+    return _BatchNormDeferred.apply(x, bn.weight, bn.bias, rm, rv, float(bn.momentum), float(bn.eps), stats)
 
 
 def conv3d_pre(x, coef, weight, stride=1, padding=0, want_stats=False):
-    y, stats = _Conv3dPre.apply(x, coef, weight, _triple(stride), _triple(padding), bool(want_stats),
-                                getattr(coef, "_zsv_bn_link", None))
+    y, stats = _Conv3dPre.apply(x, coef, weight, _triple(stride), _triple(padding), bool(want_stats))
     return (y, stats) if want_stats else y
 
 
