@@ -447,42 +447,52 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     const int c_first = NCHUNKS > 0 ? 0 : split * prm.chunks_per_split;
     const int nchunks = NCHUNKS > 0 ? NCHUNKS : min(prm.chunks_per_split, nchunks_all - c_first);
     int ld_cb = c_first / prm.R, ld_kt = (c_first % prm.R) / 3, ld_kh = c_first % 3;
-    // the DMAs of chunk `chunk` into stage `buf`: 4 image pieces (k rows 4*wave .. +3), the halo (wave 0), this wave's U pieces
-    auto issue = [&](int chunk, int buf) {
+    // the DMAs of chunk `chunk` into stage `buf`: 4 image pieces (k rows 4*wave .. +3), the halo (wave 0), this wave's U pieces --
+    // NDMA instructions, handed out one at a time (issue_piece) between the MFMAs of the chunk before: a wave's ten 1-KiB DMAs in
+    // a row waited 0.9 us of a 2.6 us chunk for the CU's address path, issuing no MFMA meanwhile (measured on the temporal kernel
+    // with tools/winot_trace.py; see conv_winot4_kernel)
+    constexpr int NDMA = 5 + APASS;
+    int is_toff = 0, is_r = 0, is_ci0 = 0;
+    unsigned is_voff = 0;
+    auto issue_begin = [&]() {
+        is_toff = 4 * ((ld_kh - 1) * prm.W + (ld_kt - prm.kT / 2) * prm.HW);
+        is_r = ld_kt * 3 + ld_kh;
+        is_ci0 = ld_cb * 16;
+        is_voff = ((hmask >> is_r) & 1u) ? (unsigned)(base_bytes + is_toff) : OOB16;
+        if (++ld_kh == 3) {
+            ld_kh = 0;
+            if (++ld_kt == prm.kT) { ld_kt = 0; ++ld_cb; }
+        }
+    };
+    auto issue_piece = [&](int chunk, int buf, int j) {
         float* us = u_of(buf);
         float* bs = img_of(buf);
-        const int toff = 4 * ((ld_kh - 1) * prm.W + (ld_kt - prm.kT / 2) * prm.HW);
-        const int ld_r = ld_kt * 3 + ld_kh;
-        const unsigned ok = (hmask >> ld_r) & 1u;
-        const int ci0 = ld_cb * 16;
-        const unsigned voff = ok ? (unsigned)(base_bytes + toff) : OOB16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0), 16, (int)(ci < prm.C ? voff : OOB16),
+        if (j < 4) {
+            const int k = 4 * wave + j, ci = is_ci0 + k;                   // wave-uniform row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB + C0), 16, (int)(ci < prm.C ? is_voff : OOB16),
                                                      ci < prm.C ? ci * ch_bytes : 0, 0, 0);
-        }
-        if (!VW && wave == 0) {
-            const int k = lane >> 1;
-            const int ci = ci0 + k;
-            const unsigned hok = (halo_mask >> ld_r) & 1u;
-            unsigned hv = (unsigned)(halo_base + toff) | (hok - 1u);
-            if (lane >= 32 || ci >= prm.C) hv = OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + B_FLOATS), 4, (int)(hv + (hv == OOB ? 0u : (unsigned)(ci * ch_bytes))), 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            const int piece = (3 - wave) + 4 * j;        // (wave 0 also carries the halo DMA: it gets the short share when the pieces do not divide)
+        } else if (j == 4) {
+            if (!VW && wave == 0) {
+                const int k = lane >> 1;
+                const int ci = is_ci0 + k;
+                const unsigned hok = (halo_mask >> is_r) & 1u;
+                unsigned hv = (unsigned)(halo_base + is_toff) | (hok - 1u);
+                if (lane >= 32 || ci >= prm.C) hv = OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + B_FLOATS), 4, (int)(hv + (hv == OOB ? 0u : (unsigned)(ci * ch_bytes))), 0, 0, 0);
+            }
+        } else {
+            const int piece = (3 - wave) + 4 * (j - 5);        // (wave 0 also carries the halo DMA: it gets the short share when the pieces do not divide)
             if (piece < NPIECES) {
                 const int pt = piece / TM, ib = piece % TM;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_ptr_t)(us + 256 * piece), 16, u_lane_bytes,
                                                          chunk * u_chunk_bytes + 4 * 16 * (pt * prm.Mp + 16 * ib), 0, 0);
             }
         }
-        if (++ld_kh == 3) {
-            ld_kh = 0;
-            if (++ld_kt == prm.kT) { ld_kt = 0; ++ld_cb; }
-        }
+    };
+    auto issue = [&](int chunk, int buf) {
+        issue_begin();
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) issue_piece(chunk, buf, j);
     };
     auto place_halo = [&](int buf) {
         if (!VW && wave == 0 && lane < 32) {
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
             __syncthreads();
         }
+        if (prefetching) issue_begin();
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int sl = s & 1;
@@ -568,13 +579,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
                     acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
+                    // one DMA instruction of the next chunk after every sixth MFMA (TM per k step; 4 * TM slots >= NDMA), from the
+                    // first burst on (at 64 rows the barrier that frees the single U panel is behind us)
+                    const int idx = p * TM + i;
+                    if (idx % 6 == 5 && s * TM + idx / 6 < NDMA && prefetching) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(c_first + ch + 1, cur ^ 1, s * TM + idx / 6);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            // the next chunk's DMAs go out after the first burst, not at the head of the chunk next to its 18 + 2 LDS reads (and, at 64 rows, after the
-            // barrier that frees the single U panel); spreading them over the later gaps leaves the last ones too little time to land (measured)
-            if (s == 0 && prefetching) issue(c_first + ch + 1, cur ^ 1);
         }
         if (!(W4ABL & 4)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -952,6 +969,21 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
 #endif
 }
 
+// Phase timestamps of conv_winot4_kernel for tools/winot_trace.py (a variant build: tools/variant.sh trace conv_wino.hip
+// -DZSV_WINOT_TRACE): wave 0 of every workgroup writes s_memtime at six points + its hardware id behind the output tensor (the
+// script allocates the room).  Never defined in the shipped library.
+// ZSV_WINOT_ABLATE (variant builds only, wrong results): 1 = no output stores, 2 = no image DMAs, 3 = no MFMAs, 4 = no U DMAs
+#ifndef ZSV_WINOT_ABLATE
+#define ZSV_WINOT_ABLATE 0
+#endif
+#ifdef ZSV_WINOT_TRACE
+#define ZSV_TRACE_MARK(i) do { if (tid == 0) trace_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ZSV_TRACE_LAP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); trace_lap[i] += now_ - trace_last; trace_last = now_; } } while (0)
+#else
+#define ZSV_TRACE_MARK(i) do { } while (0)
+#define ZSV_TRACE_LAP(i) do { } while (0)
+#endif
+
 // ================================================================================================
 // The same temporal convolution in F(4,3) form ALONG T (T % 4 == 0: every T the F(2,3) kernel takes): four frames t..t+3 of one
 // (h, w) position share the six input frames d0..d5 = in[t-1..t+4]; V, U and the output transform are conv_wino4_kernel's with T in
@@ -981,6 +1013,10 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     auto img_of = [&](int buf) -> float* { return pool + (USINGLE ? A_FLOATS + buf * IMG : buf * STAGE + A_FLOATS); };
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ZSV_WINOT_TRACE
+    unsigned long long trace_t[6], trace_lap[5] = {0, 0, 0, 0, 0}, trace_last = 0;
+#endif
+    ZSV_TRACE_MARK(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = xcd_tile(gridDim.x, blockIdx.x);          // the row tiles of one column tile are neighbours (one L2)
     const int m0 = (tile % prm.tiles_m) * BM;
@@ -995,41 +1031,45 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     const int pf = lane >> pq_log2, pp = pos0 + 4 * (lane - (pf << pq_log2));
     const unsigned piece_off = pp < HW ? (unsigned)(4 * (n_img * prm.C * prm.S + pf * HW + pp)) : OOB16;
 
+    // U panels through a buffer descriptor: one per-lane byte offset, pieces and chunks in the scalar offset
     constexpr int NPIECES = NP * TM, APASS = (NPIECES + 3) / 4;
-    const float* a_src[APASS];
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-        const int q = (3 - wave) + 4 * j, qq = q < NPIECES ? q : 0, pt = qq / TM, ib = qq % TM, row = lane >> 2;
-        const int sw = ((lane & 3) ^ (((row >> 2) & 1) << 1)) * 4;
-        a_src[j] = Up + ((size_t)pt * prm.Mp + m0 + 16 * ib + row) * 16 + sw;
-    }
-    const size_t a_chunk_stride = (size_t)NP * BK * prm.Mp;
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Up), 0, prm.u_bytes, 0x00020000);
+    const int u_lane_bytes = 4 * ((m0 + (lane >> 2)) * 16 + ((lane & 3) ^ ((((lane >> 2) >> 2) & 1) << 1)) * 4);
+    const int u_chunk_bytes = 4 * NP * BK * prm.Mp;
     const __amdgpu_buffer_rsrc_t pre_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? prm.pre_coef : IN), 0, PRE ? 8u * (unsigned)prm.pre_pitch : 0u, 0x00020000);
 
     const int nchunks = prm.nblk;
-    auto issue = [&](int chunk, int buf) {
+    // one DMA instruction of chunk `chunk` into stage `buf`: pieces 0..3 = this wave's four image rows, 4..4+APASS-1 = its U pieces,
+    // then (PRE, wave 0) the 16 scales / shifts.  Issued ONE AT A TIME between the MFMAs of the chunk before: the nine to eleven
+    // 1-KiB DMAs of a wave in a row took 0.86 us of a 2.6 us chunk to get accepted by the CU's address path (64 B / clock shared
+    // by eight waves that all ask at the chunk boundary; tools/winot_trace.py) while the wave issued no MFMA.
+    constexpr int NDMA = 4 + APASS + (PRE ? 1 : 0);
+    auto issue_piece = [&](int chunk, int buf, int j) {
         float* as = u_of(buf);
         float* bs = img_of(buf);
         const int ci0 = chunk * 16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        if (j < 4) {
+            if (ZSV_WINOT_ABLATE == 2) return;
             const int k = 4 * wave + j, ci = ci0 + k;                   // wave-uniform row
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bs + k * LDB), 16, (int)(ci < prm.C ? piece_off : OOB16),
                                                      ci < prm.C ? ci * ch_bytes : 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            const int q = (3 - wave) + 4 * j;
-            if (q < NPIECES)
-                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)chunk * a_chunk_stride, (lds_ptr_t)(as + 256 * q), 16, 0, 0);
-        }
-        if constexpr (PRE) {
+        } else if (j < 4 + APASS) {
+            const int q = (3 - wave) + 4 * (j - 4);
+            if (q < NPIECES && ZSV_WINOT_ABLATE != 4) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_u, (lds_ptr_t)(as + 256 * q), 16, u_lane_bytes,
+                                                         chunk * u_chunk_bytes + 4 * 16 * ((q / TM) * prm.Mp + 16 * (q % TM)), 0, 0);
+            }
+        } else if constexpr (PRE) {
             if (wave == 0) {
                 const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : OOB16;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(bs + B_FLOATS), 16, (int)off, 0, 0, 0);
             }
         }
+    };
+    auto issue = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) issue_piece(chunk, buf, j);
     };
 
     f32x4 acc[NP][TM];
@@ -1047,11 +1087,17 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
     const bool zero_d5 = 4 * tq + 4 >= T;                           // frame T
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
 
+    ZSV_TRACE_MARK(1);
     issue(0, 0);
     __syncthreads();                                   // (vmcnt(0) before the barrier)
+    ZSV_TRACE_MARK(2);
+#ifdef ZSV_WINOT_TRACE
+    trace_last = trace_t[2];
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (!USINGLE && ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
+        const bool prefetching = ch + 1 < nchunks;
+        ZSV_TRACE_LAP(3);
         const float* as = u_of(cur);
         const float* bs = img_of(cur);
         f32x4 a4[NP][TM];
@@ -1078,10 +1124,8 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
             }
         };
         fetch(0, 0);
-        if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
-            __syncthreads();
-            if (ch + 1 < nchunks) issue(ch + 1, cur ^ 1);
-        }
+        ZSV_TRACE_LAP(4);                              // U fragments + first image values (the mark waits for them)
+        if (USINGLE) __syncthreads();           // every wave holds the chunk's U fragments: the panel may be overwritten
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int sl = s & 1;
@@ -1101,19 +1145,33 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
             v[4] = __fmaf_rn(-2.f, u31, u42);
             v[5] = __fmaf_rn(4.f, d1, __fmaf_rn(-5.f, d3, d5));
             if (s < 3) fetch(s + 1, sl ^ 1);
+            if (s == 0) ZSV_TRACE_LAP(0);           // DMA issue, U fragments, first V: everything before the first MFMA of a chunk
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    if (ZSV_WINOT_ABLATE == 3) acc[p][i][0] += a4[p][i][s] * v[p];
+                    else acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
+                    // one DMA instruction of the next chunk after every sixth MFMA (TM per k step: 4 * TM slots >= NDMA)
+                    constexpr int NSLOT = TM;
+                    const int idx = p * TM + i;
+                    if (idx % 6 == 5 && s * NSLOT + idx / 6 < NDMA && prefetching) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(ch + 1, cur ^ 1, s * NSLOT + idx / 6);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        ZSV_TRACE_LAP(1);                              // the four k steps (transforms + 72 / 96 MFMAs)
         __syncthreads();                               // (vmcnt(0) lgkmcnt(0) + barrier)
+        ZSV_TRACE_LAP(2);                              // waiting for the next chunk's DMAs and the other waves
     }
 
+    ZSV_TRACE_MARK(3);
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + store: lane holds rows 4g..4g+3 of quad column r16 of its block
     const int pos = pos0 + col;
     const bool ok = pos < HW;
@@ -1142,7 +1200,9 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
                 }
                 const int soff = (16 * i + r) * row_bytes;
 #pragma unroll
-                for (int f = 0; f < 4; ++f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[f]), orsrc, (int)voff, soff + f * frame_bytes, 0);
+                for (int f = 0; f < 4; ++f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[f]), orsrc, (int)(ZSV_WINOT_ABLATE == 1 && y[f] != 123.456f ? OOB : voff),
+                                                          soff + f * frame_bytes, 0);
                 if constexpr (EPI == 1) {
                     float s1 = live ? (y[0] + y[1]) + (y[2] + y[3]) : 0.f;
                     float s2 = live ? (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]) : 0.f;
@@ -1208,6 +1268,20 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
             prm.stat_sq[(size_t)(m0 + tid) * prm.tiles_n + ct] = t2;
         }
     }
+#ifdef ZSV_WINOT_TRACE
+    ZSV_TRACE_MARK(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZSV_TRACE_MARK(5);
+    if (tid == 0) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(OUT + (prm.out_bytes >> 2)) + (size_t)blockIdx.x * 12;
+        for (int i = 0; i < 6; ++i) rec[i] = trace_t[i];
+        rec[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                 (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // XCC_ID : HW_ID
+        rec[7] = (unsigned long long)tile;
+        for (int i = 0; i < 3; ++i) rec[8 + i] = trace_lap[i];
+        rec[11] = (trace_lap[3] << 32) | (trace_lap[4] & 0xFFFFFFFFull);
+    }
+#endif
 #endif
 }
 
@@ -1432,6 +1506,7 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     if (!panel_place(wino_bytes(d, M, C), workspace, up, pst)) return pst;
     const bool f43 = ZSV_KNOB(WINOT_NO_F43) == nullptr;          // (T is 4, 8 or 16 here: whole frame quads)
     const long total = (long)p.nblk * (f43 ? 6 : 4) * 16 * p.Mp;
+    p.u_bytes = (unsigned)(total * sizeof(float));
     if (g_panel.mode == PANEL_RECORD) {
         pack_job_wino(g_panel.job, f43 ? 6 : 4, PackWinoArgs{p.M, p.Mp, p.C, p.nblk, 1, flip, sm, sc}, w, up, total);
         g_panel.jobs++;
