@@ -657,6 +657,7 @@ class _BatchNormDeferred(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, stats):
+        ctx.set_materialize_grads(False)
         _require(x, gamma, beta, running_mean, running_var, stats)
         if not x.is_contiguous():
             raise RuntimeError("deferred BatchNorm needs a contiguous input")
@@ -692,6 +693,8 @@ class _BatchNormDeferred(Function):
         x, gamma, beta, save_mean, save_invstd = ctx.saved_tensors
         n, c, s = ctx.dims
         lib = _lib.load()
+        if g is None:                           # output unused downstream
+            return (None,) * 8
         g = g.contiguous()
         dx = torch.empty_like(x)
         dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
@@ -712,6 +715,7 @@ class _Conv3dPre(Function):
 
     @staticmethod
     def forward(ctx, x, coef, weight, stride, padding, want_stats):
+        ctx.set_materialize_grads(False)
         _require(x, coef, weight)
         weight = weight.contiguous()
         d = conv_desc(x.shape, weight.shape, stride, padding)
