@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
 // per 7 outputs against 21 (1.75x fewer MFMAs than the direct kernel they used to take); 14-wide rows 24 per 14 against the
 // F(2,3) kernel's 28, with 16-byte image DMAs instead of 4-byte ones.
 // EPI: the epilogue, chosen at compile time (as conv_winot4_kernel): bit 0 = BatchNorm partial statistics, bit 1 = + add (the
-// identity-shortcut gradient of zsv_conv3d_dgrad_add), 4 = the run-time-flag form (bias / ReLU / residual of the inference engine).
+// identity-shortcut gradient of zsv_conv3d_dgrad_add), 8 = relu(result + bias[m]) (C3D's forward convolutions, folded-BatchNorm
+// inference without a residual), 4 = the run-time-flag form (every other bias / ReLU / residual combination).
 // EPI < 4 is branch-free: 16-byte buffer stores (and loads of `add`) with scalar row offsets, lanes outside the problem dropped by
 // the descriptor's range check.
 template <int TM, int NCHUNKS, bool VW = false, int EPI = 4>
@@ -602,13 +603,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     if ((W4ABL & 8) && prm.P > 0) return;
 
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + 16-byte stores: lane holds rows 4g..4g+3 of quad column r16
-    if constexpr (EPI < 4) {
-        constexpr bool STATS = (EPI & 1) != 0, ADD = (EPI & 2) != 0;
+    if constexpr (EPI != 4) {
+        constexpr bool STATS = EPI < 4 && (EPI & 1) != 0, ADD = EPI < 4 && (EPI & 2) != 0, BIASRELU = EPI == 8;
         constexpr unsigned OOBS = 0xFFFFFFF0u;
         float* red = pool;
         if (STATS) __syncthreads();
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(OUT, 0, prm.out_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? prm.add : IN), 0, ADD ? prm.out_bytes : 0u, 0x00020000);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t brsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BIASRELU ? prm.bias : IN), 0, BIASRELU ? 4u * (unsigned)prm.M : 0u, 0x00020000);
         // byte offset of (row m0 + 4g, this quad); rows 16 i + r go into the scalar offset
         const unsigned lane_off = quad_ok ? 4u * (unsigned)(n_clip * prm.M * prm.S + sp_first + (m0 + 4 * g) * prm.S) : OOBS;
         const bool ragged = m0 + BM > prm.M;                  // (wave-uniform)
@@ -659,6 +662,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
                     if (r16 == 0) *reinterpret_cast<f32x2*>(&red[(wave * BM + 16 * i + 4 * g + r) * 2]) = f32x2{s1, s2};
                 }
                 if constexpr (ADD) y += addv[r];
+                if constexpr (BIASRELU) {                   // relu(conv + bias[m]) (C3D's forward, network.py:147-166; folded-BatchNorm inference)
+                    const float bv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(brsrc, 4 * (m0 + 16 * i + 4 * g + r), 0, 0));      // (rows beyond M read 0)
+                    y[0] = fmaxf(y[0] + bv, 0.f); y[1] = fmaxf(y[1] + bv, 0.f); y[2] = fmaxf(y[2] + bv, 0.f); y[3] = fmaxf(y[3] + bv, 0.f);
+                }
                 const int soff = (16 * i + r) * row_bytes;
                 if (!VW || nvalid >= 4) {
                     // The row offset goes into the VECTOR offset here (one add), not into the scalar offset as for the 4-byte
@@ -1446,6 +1453,8 @@ static int wino4_launch_epi(const WinoParams& p, const float* up, const float* i
 }
 template <int TM, int NCHUNKS, bool VW = false>
 static int wino4_launch(const WinoParams& p, const float* up, const float* in, float* out, hipStream_t stream) {
+    if (p.bias != nullptr && p.relu && p.add == nullptr && p.stat_sum == nullptr && ZSV_KNOB(WINO_GENERIC_EPILOGUE) == nullptr)
+        return wino4_launch_epi<TM, NCHUNKS, VW, 8>(p, up, in, out, stream);
     if (p.bias != nullptr || p.relu || (p.add != nullptr && p.stat_sum != nullptr) || ZSV_KNOB(WINO_GENERIC_EPILOGUE))
         return wino4_launch_epi<TM, NCHUNKS, VW, 4>(p, up, in, out, stream);
     if (p.add != nullptr) return wino4_launch_epi<TM, NCHUNKS, VW, 2>(p, up, in, out, stream);
