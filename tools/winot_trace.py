@@ -15,7 +15,9 @@ from zeroshotvideoclassification_amd import _lib, ops  # noqa: E402
 
 DEV = torch.device("cuda:0")
 SHAPES = {"T1": ((22, 144, 16, 56, 56), 64), "T3": ((22, 230, 8, 28, 28), 128), "T4": ((22, 288, 8, 28, 28), 128),
-          "T6": ((22, 460, 4, 14, 14), 256)}
+          "T6": ((22, 460, 4, 14, 14), 256),
+          # spatial 1x3x3 layers (conv_wino4_kernel): (input shape, output channels)
+          "S1": ((22, 64, 16, 56, 56), 144), "S3": ((22, 128, 8, 28, 28), 230), "S4": ((22, 128, 8, 28, 28), 288)}
 
 
 def main():
@@ -24,11 +26,12 @@ def main():
     xs, cout = SHAPES[name]
     n, c, t, h, w = xs
     lib = _lib.load()
-    wt = torch.randn(cout, c, 3, 1, 1, device=DEV) / (3 * c) ** 0.5
-    d = ops.conv_desc(xs, wt.shape, 1, (1, 0, 0))
+    spatial = name.startswith("S")
+    wt = torch.randn(*((cout, c, 1, 3, 3) if spatial else (cout, c, 3, 1, 1)), device=DEV) / (3 * c) ** 0.5
+    d = ops.conv_desc(xs, wt.shape, 1, (0, 1, 1) if spatial else (1, 0, 0))
     ys = (n, cout, t, h, w)
     global NCHUNKS
-    NCHUNKS = ((cout if kind == "dgrad" else c) + 15) // 16
+    NCHUNKS = ((cout if kind == "dgrad" else c) + 15) // 16 * (3 if spatial else 1)
     src_shape, out_shape = (ys, xs) if kind == "dgrad" else (xs, ys)
     src = torch.randn(*src_shape, device=DEV)
     out_elems = int(np.prod(out_shape))

@@ -354,6 +354,24 @@ __global__ __launch_bounds__(256) void wino4_pack_kernel(const float* __restrict
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Up[i] = pack_wino_value<6>(a, W, i);
 }
 
+// Phase timestamps of conv_wino4_kernel / conv_winot4_kernel for tools/winot_trace.py (a variant build: tools/variant.sh trace conv_wino.hip
+// -DZSV_WINOT_TRACE): wave 0 of every workgroup writes s_memtime at six points + its hardware id behind the output tensor (the
+// script allocates the room).  Never defined in the shipped library.
+// ZSV_WINOT_ABLATE (variant builds only, wrong results): 1 = no output stores, 2 = no image DMAs, 3 = no MFMAs, 4 = no U DMAs
+#ifndef ZSV_WINOT_ABLATE
+#define ZSV_WINOT_ABLATE 0
+#endif
+#ifdef ZSV_WINOT_TRACE
+#define ZSV_TRACE_MARK(i) do { if (tid == 0) trace_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ZSV_TRACE_LAP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); trace_lap[i] += now_ - trace_last; trace_last = now_; } } while (0)
+#else
+#define ZSV_TRACE_MARK(i) do { } while (0)
+#define ZSV_TRACE_LAP(i) do { } while (0)
+#endif
+
+#ifndef ZSV_DMA_EVERY
+#define ZSV_DMA_EVERY 6          // MFMAs between two DMA instructions of the next chunk (conv_wino4_kernel / conv_winot4_kernel)
+#endif
 #ifndef W4ABL
 #define W4ABL 0        // timing-only ablation builds (tools/variant.sh): 1 no DMAs after the first chunk, 2 no fragment reads, 4 no chunk-end wait / barrier, 8 no stores
 #endif
@@ -387,6 +405,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     auto img_of = [&](int buf) -> float* { return pool + (USINGLE ? A_FLOATS + buf * IMG : buf * STAGE + A_FLOATS); };
 
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef ZSV_WINOT_TRACE
+    unsigned long long trace_t[6], trace_lap[5] = {0, 0, 0, 0, 0}, trace_last = 0;
+#endif
+    ZSV_TRACE_MARK(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lid = xcd_tile(gridDim.x, blockIdx.x);
     const int tile = (int)mdiv((unsigned)lid, prm.m_ksplit), split = lid - tile * prm.ksplit;
@@ -521,12 +543,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
     const int nvalid = VW ? prm.W - w_first : 4;                    // VW: real voxels of the quad (1..4 at a row's end; W > Wv - 4)
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
 
+    ZSV_TRACE_MARK(1);
     issue(c_first, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     place_halo(0);
     __syncthreads();
+    ZSV_TRACE_MARK(2);
+#ifdef ZSV_WINOT_TRACE
+    trace_last = trace_t[2];
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
+        ZSV_TRACE_LAP(3);
         const bool prefetching = ch + 1 < nchunks && !(W4ABL & 1);
         const float* as = u_of(cur);
         const float* bs = img_of(cur);
@@ -549,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             de[slot] = src[r16 == 0 ? -1 : 4];           // (used by lanes 0 and 15 of a row only)
         };
         fetch(0, 0);
+        ZSV_TRACE_LAP(4);
         if (USINGLE) {                          // every wave holds the chunk's U fragments: the panel may be overwritten
             __syncthreads();
         }
@@ -575,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
             v[4] = __fmaf_rn(-2.f, u31, u42);
             v[5] = __fmaf_rn(4.f, d1, __fmaf_rn(-5.f, d3, d5));
             if (s < 3) fetch(s + 1, sl ^ 1);
+            if (s == 0) ZSV_TRACE_LAP(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -582,25 +612,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
-                    // one DMA instruction of the next chunk after every sixth MFMA (TM per k step; 4 * TM slots >= NDMA), from the
-                    // first burst on (at 64 rows the barrier that frees the single U panel is behind us)
+                    // one DMA instruction of the next chunk after every ZSV_DMA_EVERY-th MFMA, from the first burst on (at 64 rows
+                    // the barrier that frees the single U panel is behind us)
+                    constexpr int EV = ZSV_DMA_EVERY, PER_STEP = (NP * TM) / EV;
+                    static_assert(4 * PER_STEP >= NDMA, "a slot for every DMA instruction of a chunk");
                     const int idx = p * TM + i;
-                    if (idx % 6 == 5 && s * TM + idx / 6 < NDMA && prefetching) {
+                    if (idx % EV == EV - 1 && idx / EV < PER_STEP && s * PER_STEP + idx / EV < NDMA && prefetching) {
                         __builtin_amdgcn_sched_barrier(0);
-                        issue_piece(c_first + ch + 1, cur ^ 1, s * TM + idx / 6);
+                        issue_piece(c_first + ch + 1, cur ^ 1, s * PER_STEP + idx / EV);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        ZSV_TRACE_LAP(1);
         if (!(W4ABL & 4)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (ch + 1 < nchunks) place_halo(cur ^ 1);
         __syncthreads();
         }
+        ZSV_TRACE_LAP(2);
     }
     if ((W4ABL & 8) && prm.P > 0) return;
+    ZSV_TRACE_MARK(3);
 
     // ---- output transform (+ statistics) (+ add, bias, ReLU) + 16-byte stores: lane holds rows 4g..4g+3 of quad column r16
     if constexpr (EPI != 4) {
@@ -753,6 +788,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(WinoParams prm, cons
         }
     }
     }
+#ifdef ZSV_WINOT_TRACE
+    ZSV_TRACE_MARK(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZSV_TRACE_MARK(5);
+    if (tid == 0) {
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(OUT + (prm.out_bytes >> 2)) + (size_t)blockIdx.x * 12;
+        for (int i = 0; i < 6; ++i) rec[i] = trace_t[i];
+        rec[6] = (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_ID
+        rec[7] = (unsigned long long)tile;
+        for (int i = 0; i < 3; ++i) rec[8 + i] = trace_lap[i];
+        rec[11] = (trace_lap[3] << 32) | (trace_lap[4] & 0xFFFFFFFFull);
+    }
+#endif
 #endif
 }
 
@@ -976,21 +1024,6 @@ __global__ __launch_bounds__(256, 2) void conv_winot_kernel(WinoParams prm, cons
 #endif
 }
 
-// Phase timestamps of conv_winot4_kernel for tools/winot_trace.py (a variant build: tools/variant.sh trace conv_wino.hip
-// -DZSV_WINOT_TRACE): wave 0 of every workgroup writes s_memtime at six points + its hardware id behind the output tensor (the
-// script allocates the room).  Never defined in the shipped library.
-// ZSV_WINOT_ABLATE (variant builds only, wrong results): 1 = no output stores, 2 = no image DMAs, 3 = no MFMAs, 4 = no U DMAs
-#ifndef ZSV_WINOT_ABLATE
-#define ZSV_WINOT_ABLATE 0
-#endif
-#ifdef ZSV_WINOT_TRACE
-#define ZSV_TRACE_MARK(i) do { if (tid == 0) trace_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define ZSV_TRACE_LAP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); trace_lap[i] += now_ - trace_last; trace_last = now_; } } while (0)
-#else
-#define ZSV_TRACE_MARK(i) do { } while (0)
-#define ZSV_TRACE_LAP(i) do { } while (0)
-#endif
-
 // ================================================================================================
 // The same temporal convolution in F(4,3) form ALONG T (T % 4 == 0: every T the F(2,3) kernel takes): four frames t..t+3 of one
 // (h, w) position share the six input frames d0..d5 = in[t-1..t+4]; V, U and the output transform are conv_wino4_kernel's with T in
@@ -1161,12 +1194,13 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
                 for (int i = 0; i < TM; ++i) {
                     if (ZSV_WINOT_ABLATE == 3) acc[p][i][0] += a4[p][i][s] * v[p];
                     else acc[p][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[p][i][s], v[p], acc[p][i], 0, 0, 0);
-                    // one DMA instruction of the next chunk after every sixth MFMA (TM per k step: 4 * TM slots >= NDMA)
-                    constexpr int NSLOT = TM;
+                    // one DMA instruction of the next chunk after every ZSV_DMA_EVERY-th MFMA
+                    constexpr int EV = ZSV_DMA_EVERY, PER_STEP = (NP * TM) / EV;
+                    static_assert(4 * PER_STEP >= NDMA, "a slot for every DMA instruction of a chunk");
                     const int idx = p * TM + i;
-                    if (idx % 6 == 5 && s * NSLOT + idx / 6 < NDMA && prefetching) {
+                    if (idx % EV == EV - 1 && idx / EV < PER_STEP && s * PER_STEP + idx / EV < NDMA && prefetching) {
                         __builtin_amdgcn_sched_barrier(0);
-                        issue_piece(ch + 1, cur ^ 1, s * NSLOT + idx / 6);
+                        issue_piece(ch + 1, cur ^ 1, s * PER_STEP + idx / EV);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
