@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include "zsv_hip.h"
 #include "zsv_common.h"
+#include "knobs.h"
 
 namespace zsv {
 
@@ -252,7 +253,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            double* __restrict__ part) {
+                                                            double* __restrict__ part, float* __restrict__ gout) {
+    // gout != nullptr (RELU 1 with a residual branch): the masked gradient g = dy * (y > 0) is written here -- it IS the gradient of
+    // the residual branch -- and the apply pass then reads g alone instead of dy and y again (8 -> 7 passes over the tensor)
     __shared__ double red[4];
     const int c = blockIdx.x, sl = blockIdx.y;
     const bool vec = (S % 4) == 0;
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 g.x = __fmaf_rn(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = __fmaf_rn(xv.y, sc, sh) > 0.f ? g.y : 0.f;
                 g.z = __fmaf_rn(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = __fmaf_rn(xv.w, sc, sh) > 0.f ? g.w : 0.f;
             }
+            if (RELU == 1 && gout) *reinterpret_cast<float4*>(gout + off) = g;
             s1 += (g.x + g.y) + (g.z + g.w);
             s2 += (g.x * ((xv.x - mu) * is) + g.y * ((xv.y - mu) * is)) +
                   (g.z * ((xv.z - mu) * is) + g.w * ((xv.w - mu) * is));
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             float g = dy[off];
             if (RELU == 1) g = y[off] > 0.f ? g : 0.f;
             else if (RELU == 2) g = __fmaf_rn(x[off], sc, sh) > 0.f ? g : 0.f;
+            if (RELU == 1 && gout) gout[off] = g;
             s1 += g;
             s2 += g * ((x[off] - mu) * is);
         }
@@ -533,18 +538,26 @@ extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32
     const int slices = bn_slices(N, C, S);
     BnWs w = bn_ws(workspace, C, slices);
     const dim3 rgrid(C, slices);
+    // fuse_relu 1 with a residual gradient: the reduction writes the masked gradient (= d_residual), the apply pass reads it (mode 0)
+    const bool g_from_reduce = fuse_relu == 1 && d_residual != nullptr && ZSV_KNOB(BN_NO_MASKED_G) == nullptr;
     if (fuse_relu == 2)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr);
     else if (fuse_relu == 1)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part,
+                           g_from_reduce ? d_residual : (float*)nullptr);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr);
     if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C, slices,
                        (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
     if ((st = launch_status())) return st;
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
 #define ZSV_BWD_APPLY(R, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, D>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1, gamma, save_invstd, w.c2)
+    if (g_from_reduce) {
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false>), grid, dim3(256), 0, stream, (const float*)d_residual, x, y, dx, (float*)nullptr, C, S, w.scale, w.shift, w.c1,
+                           gamma, save_invstd, w.c2);
+        return launch_status();
+    }
     if (fuse_relu == 2) { if (d_residual) ZSV_BWD_APPLY(2, true); else ZSV_BWD_APPLY(2, false); }
     else if (fuse_relu == 1) { if (d_residual) ZSV_BWD_APPLY(1, true); else ZSV_BWD_APPLY(1, false); }
     else { if (d_residual) ZSV_BWD_APPLY(0, true); else ZSV_BWD_APPLY(0, false); }
