@@ -219,6 +219,10 @@ class _PanelCache:
         self.stream = None
         self.lock = threading.RLock()
         self.repacks = 0             # multi-pack launches so far (tests / diagnostics)
+        self.nbytes = 0              # bytes of all panels held
+        # a panel exists per (weight, geometry): a caller that keeps changing clip shapes would grow the cache without bound, so it
+        # is emptied (and refills with the shapes in use) once it holds more than this
+        self.limit = int(os.environ.get("ZSV_PANEL_CACHE_MB", "8192")) << 20
 
     @staticmethod
     def _version(w):
@@ -230,6 +234,7 @@ class _PanelCache:
         with self.lock:
             if self.knob_gen != _lib.knob_generation():          # the switches changed: layouts may have too
                 self.entries.clear()
+                self.nbytes = 0
                 self.table = None
                 self.knob_gen = _lib.knob_generation()
             key = (id(weight), direction, extras) + d.key
@@ -237,9 +242,14 @@ class _PanelCache:
             if e is not False and e is not None and e.weight() is not weight:
                 e = False                                        # (the id was recycled by another tensor)
             if e is False:
+                if self.nbytes > self.limit:
+                    self.entries.clear()
+                    self.nbytes = 0
                 e = self._create(weight, d, direction, extras, weakref)
                 self.entries[key] = e
                 self.table = None
+                if e is not None:
+                    self.nbytes += e.nbytes
             if e is None:
                 return None
             if e.version != self._version(weight):
@@ -290,6 +300,7 @@ class _PanelCache:
                     self.table = None
                 stale.append((key, e, v))
         for key in dead:
+            self.nbytes -= self.entries[key].nbytes
             del self.entries[key]
             self.table = None
         if not stale:
