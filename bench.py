@@ -204,6 +204,7 @@ def parse(argv=None):
                     help="seconds after which ranks that are still running are stopped and the run fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C3D / 32-frame bf16 eval legs after the timed region")
+    ap.add_argument("--no-phases", action="store_true", help="skip the forward-only / forward+backward legs (counter passes over whole steps)")
     ap.add_argument("--cpu-steps", type=int, default=12)
     return ap.parse_args(argv)
 
@@ -549,7 +550,7 @@ def main():
     # SURVEY 8d also asks for the forward-only and forward+backward times: measured AFTER the timed
     # region (N = 1 only), never part of `value`
     phases = None
-    if world == 1 and feeder is None:
+    if world == 1 and feeder is None and not args.no_phases:
         def timed(fn, iters=5):
             fn()
             torch.cuda.synchronize()
