@@ -731,18 +731,29 @@ def test_weight_panel_cache_is_the_same_bits_and_follows_the_weights(monkeypatch
             assert torch.equal(ga[k], gb[k]), k
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
-    # a raw write (no version bump) followed by note_raw_write(): the next forward uses the new weights
+    # a raw write (no version bump) followed by note_raw_write(): the next forward uses the new weights (with the cache switched on
+    # for inference; by default calls without autograd pack per call, so that `.data` edits of an eval model need no announcement)
     model.load_state_dict(weights)
     model.eval()
+    w = model.model.layer1[0].conv1[0][0].weight
     with torch.no_grad():
         y0 = train.embed(model, xd).clone()
-        w = model.model.layer1[0].conv1[0][0].weight
+        w0 = w.data.clone()
         w.data.mul_(1.5)
+        w15 = w.data.clone()
+        y1_plain = train.embed(model, xd).clone()             # (no note_raw_write, no cache: already right)
+        monkeypatch.setenv("ZSV_PANEL_CACHE_EVAL", "1")
+        train.embed(model, xd)                                # panels of the 1.5x weights are cached now
+        w.data.copy_(w0 * 2.0)
         _lib.note_raw_write()
-        y1 = train.embed(model, xd).clone()
+        y2 = train.embed(model, xd).clone()
+        monkeypatch.delenv("ZSV_PANEL_CACHE_EVAL")
         monkeypatch.setenv("ZSV_NO_PANEL_CACHE", "1")
+        y2_ref = train.embed(model, xd).clone()
+        w.data.copy_(w15)
         y1_ref = train.embed(model, xd).clone()
-    assert not torch.equal(y0, y1) and torch.equal(y1, y1_ref)
+    assert not torch.equal(y0, y1_plain) and torch.equal(y1_plain, y1_ref)
+    assert not torch.equal(y1_plain, y2) and torch.equal(y2, y2_ref)
 
 
 def test_weight_panel_cache_is_bounded(monkeypatch):
@@ -754,6 +765,7 @@ def test_weight_panel_cache_is_bounded(monkeypatch):
     model.eval()
     ops.invalidate_panels()
     monkeypatch.setenv("ZSV_PANEL_CACHE_MB", "1")
+    monkeypatch.setenv("ZSV_PANEL_CACHE_EVAL", "1")           # (the cache is off without autograd by default)
     outs = {}
     with torch.no_grad():
         for rep in range(2):

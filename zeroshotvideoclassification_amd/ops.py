@@ -10,6 +10,7 @@ What each op replaces in the reference is cited next to it.
 from __future__ import annotations
 
 import os
+import threading
 
 from ctypes import byref, c_size_t, c_void_p
 from typing import Optional, Sequence, Tuple
@@ -328,8 +329,22 @@ class _PanelCache:
 _PANEL_CACHES = {}
 
 
-def _panel_for(weight, d, direction, extras):
+_call_state = threading.local()       # .recording: autograd's grad mode at the public entry point (a Function's forward always runs without it)
+
+
+def _recording() -> bool:
+    return getattr(_call_state, "recording", True)
+
+
+def _panel_for(weight, d, direction, extras, recording=True):
+    """``recording``: the call is part of an autograd graph (a forward whose inputs need gradients, or any backward)."""
     if os.environ.get("ZSV_NO_PANEL_CACHE"):
+        return None
+    # Without autograd (inference, evaluation) every call packs its own panel, as before: a change of `weight` is seen through
+    # its version counter, and writes through a `.data` alias (EMA copies, pruning, hand-made weight edits -- the things people do
+    # to an eval model) bump none.  In a training loop the next forward after `optimizer.step()` re-packs from whatever the weights
+    # hold by then, so `.data` edits between the step and that forward are picked up.  ZSV_PANEL_CACHE_EVAL=1 caches there too.
+    if not recording and not os.environ.get("ZSV_PANEL_CACHE_EVAL"):
         return None
     key = weight.device.index
     cache = _PANEL_CACHES.get(key)
@@ -416,7 +431,7 @@ class _Conv3d(Function):
                 if tiles > 0:
                     stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
             ev = timer.start() if (timer is not None and timer.wants("conv_fwd", d)) else None
-            panel = _panel_for(weight, d, 0, bias is not None or relu or stats is not None)
+            panel = _panel_for(weight, d, 0, bias is not None or relu or stats is not None, _recording())
             if panel is None:
                 _lib.check(lib.zsv_conv3d_fwd_stats(byref(d), x.data_ptr(), weight.data_ptr(), _ptr(bias), y.data_ptr(),
                                                     1 if relu else 0, _ptr(stats), tiles, _ptr(ws), nbytes, _stream()),
@@ -544,6 +559,7 @@ def conv3d(x, weight, bias=None, stride=1, padding=0, relu=False, want_stats=Fal
     src = x.__dict__.pop("_zsv_down_src", None) if hasattr(x, "__dict__") else None
     if not (torch.is_grad_enabled() and x.requires_grad):
         link = down = src = None
+    _call_state.recording = torch.is_grad_enabled()
     y, stats = _Conv3d.apply(x, weight, bias, _triple(stride), _triple(padding), bool(relu), bool(want_stats), link, down, src)
     return (y, stats) if want_stats else y
 
@@ -742,7 +758,7 @@ class _Conv3dPre(Function):
                 tiles = lib.zsv_conv3d_fwd_stat_tiles(byref(d), y.data_ptr())
                 if tiles > 0:
                     stats = torch.empty((2, d.Cout, tiles), dtype=torch.float32, device=x.device)
-            panel = _panel_for(weight, d, 0, False)
+            panel = _panel_for(weight, d, 0, False, _recording())
             if panel is None:
                 _lib.check(lib.zsv_conv3d_fwd_pre(byref(d), x.data_ptr(), coef.data_ptr(), int(coef.shape[1]), weight.data_ptr(),
                                                   y.data_ptr(), _ptr(stats), tiles, _ptr(ws), nbytes, _stream()), "zsv_conv3d_fwd_pre")
@@ -814,6 +830,7 @@ def bn_module_deferred(x, bn: torch.nn.Module, stats=None):
 
 
 def conv3d_pre(x, coef, weight, stride=1, padding=0, want_stats=False):
+    _call_state.recording = torch.is_grad_enabled()
     y, stats = _Conv3dPre.apply(x, coef, weight, _triple(stride), _triple(padding), bool(want_stats))
     return (y, stats) if want_stats else y
 
