@@ -69,25 +69,10 @@ __device__ __forceinline__ float pack_wino_value(const PackWinoArgs& a, const fl
 // `t` indexes the triples in the panel's own order with the point axis removed; values are pack_wino_value's, bit for bit.
 template <int NP>
 __device__ __forceinline__ void pack_wino_triple(const PackWinoArgs& a, const float* __restrict__ W, float* __restrict__ out, long t) {
-    // Neighbouring threads take neighbouring triples along the axis that is CLOSER in the weight tensor: the 16 channels of a block
-    // where channels are the inner axis (forward: sc = 3R floats apart), 16 rows where rows are (input gradients: the panel's rows are
-    // the convolution's input channels, sm = 3R, while its channels are Cin * 3R apart -- one 12-byte read per 64-byte sector, 5x the
-    // weights in HBM reads, when threads walk the channels there).  The 256 triples of a (16 rows x 16 channels) block are the same
-    // set either way, and so are the values: the panel is bit-identical.
-    int c16, m;
-    long r;
-    if (a.sc > a.sm) {
-        const int m_lo = (int)(t % 16);
-        c16 = (int)((t / 16) % 16);
-        r = t / 256;
-        m = (int)(r % (a.Mp / 16)) * 16 + m_lo;
-        r /= a.Mp / 16;
-    } else {
-        c16 = (int)(t % 16);
-        r = t / 16;
-        m = (int)(r % a.Mp);
-        r /= a.Mp;
-    }
+    const int c16 = (int)(t % 16);
+    long r = t / 16;
+    const int m = (int)(r % a.Mp);
+    r /= a.Mp;
     const int kh = (int)(r % a.R);
     const int cb = (int)(r / a.R);
     const int c = cb * 16 + c16;
