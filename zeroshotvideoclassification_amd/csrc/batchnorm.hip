@@ -15,11 +15,40 @@
 // summed in fixed order, so results are bitwise reproducible run to run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "zsv_hip.h"
 #include "zsv_common.h"
 #include "knobs.h"
 
 namespace zsv {
+
+// Streaming accesses with the non-temporal hint (`nt`, wave-uniform): the big activation tensors are read once per pass, and their
+// lines only push out what the kernels running next to these passes still need (the side queue's weight-gradient kernels and
+// their weight panels).  Threshold sweep inside the training step (one device, two rounds each): off 39.06 / 39.13 ms, 200 MB
+// 38.87 / 38.89, 100 MB 38.88 / 38.87 (38.78 / 38.76 on another device), 30 MB 38.79 / 38.78, every tensor 38.83 / 38.84.
+typedef float bn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p, bool nt) {
+    if (nt) {
+        const bn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bn_v4f*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, const float4& v, bool nt) {
+    if (nt) {
+        const bn_v4f w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<bn_v4f*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+// bytes of ONE tensor of the pass above which its accesses are streamed (ZSV_BN_NT_MB: default 64; 0 = never)
+static inline bool bn_stream(int N, int C, int S) {
+    const char* e = ZSV_KNOB(BN_NT_MB);
+    const double mb = e ? atof(e) : 64.0;
+    return mb > 0.0 && (double)N * C * S * 4.0 > mb * 1e6;
+}
+
 
 // slices per channel so that every channel has enough workgroups in flight and a thread
 // accumulates a bounded number of fp32 terms
@@ -197,7 +226,7 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                        float* __restrict__ y, int C, int S,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift) {
+                                                       const float* __restrict__ shift, bool nt) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float sc = scale[c], sh = shift[c];
@@ -208,10 +237,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         // full chunk: all 4 (8 with a residual) 16-byte loads of a thread are issued before the first use
         float4 v[4], r[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(x + base + s0 + 4 * threadIdx.x + 1024 * i);
+        for (int i = 0; i < 4; ++i) v[i] = ld4(x + base + s0 + 4 * threadIdx.x + 1024 * i, nt);
         if (RES) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const float4*>(res + base + s0 + 4 * threadIdx.x + 1024 * i);
+            for (int i = 0; i < 4; ++i) r[i] = ld4(res + base + s0 + 4 * threadIdx.x + 1024 * i, nt);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -219,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             v[i].z = __fmaf_rn(v[i].z, sc, sh); v[i].w = __fmaf_rn(v[i].w, sc, sh);
             if (RES) { v[i].x += r[i].x; v[i].y += r[i].y; v[i].z += r[i].z; v[i].w += r[i].w; }
             if (RELU) { v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f); }
-            *reinterpret_cast<float4*>(y + base + s0 + 4 * threadIdx.x + 1024 * i) = v[i];
+            st4(y + base + s0 + 4 * threadIdx.x + 1024 * i, v[i], nt);
         }
     } else if ((S % 4) == 0) {
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            double* __restrict__ part, float* __restrict__ gout) {
+                                                            double* __restrict__ part, float* __restrict__ gout, bool nt) {
     // gout != nullptr (RELU 1 with a residual branch): the masked gradient g = dy * (y > 0) is written here -- it IS the gradient of
     // the residual branch -- and the apply pass then reads g alone instead of dy and y again (8 -> 7 passes over the tensor)
     __shared__ double red[4];
@@ -269,10 +298,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (int i = b + 4 * (int)threadIdx.x; i < e; i += 4 * 256) {
             const int n = i / S, s = i - n * S;
             const size_t off = ((size_t)n * C + c) * S + s;
-            float4 g = *reinterpret_cast<const float4*>(dy + off);
-            const float4 xv = *reinterpret_cast<const float4*>(x + off);
+            float4 g = ld4(dy + off, nt);
+            const float4 xv = ld4(x + off, nt);
             if (RELU == 1) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + off);
+                const float4 yv = ld4(y + off, nt);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
             } else if (RELU == 2) {
@@ -346,7 +375,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ ca, const float* __restrict__ cb,
                                                            const float* __restrict__ ck, const float* __restrict__ gamma,
                                                            const float* __restrict__ invstd,
-                                                           const float* __restrict__ csh) {
+                                                           const float* __restrict__ csh, bool nt) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float a = ca[c], b = cb[c], k = ck[c];
@@ -360,9 +389,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         float4 gv[4], xq[4], yq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            gv[i] = *reinterpret_cast<const float4*>(dy + base + s0 + 4 * threadIdx.x + 1024 * i);
-            xq[i] = *reinterpret_cast<const float4*>(x + base + s0 + 4 * threadIdx.x + 1024 * i);
-            if (RELU == 1) yq[i] = *reinterpret_cast<const float4*>(y + base + s0 + 4 * threadIdx.x + 1024 * i);
+            gv[i] = ld4(dy + base + s0 + 4 * threadIdx.x + 1024 * i, nt);
+            xq[i] = ld4(x + base + s0 + 4 * threadIdx.x + 1024 * i, nt);
+            if (RELU == 1) yq[i] = ld4(y + base + s0 + 4 * threadIdx.x + 1024 * i, nt);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -377,11 +406,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 g.x = __fmaf_rn(xv.x, sc, sh) > 0.f ? g.x : 0.f; g.y = __fmaf_rn(xv.y, sc, sh) > 0.f ? g.y : 0.f;
                 g.z = __fmaf_rn(xv.z, sc, sh) > 0.f ? g.z : 0.f; g.w = __fmaf_rn(xv.w, sc, sh) > 0.f ? g.w : 0.f;
             }
-            if (DRES) *reinterpret_cast<float4*>(dres + base + s) = g;
+            if (DRES) st4(dres + base + s, g, nt);
             float4 o;
             o.x = a * g.x + b * xv.x + k; o.y = a * g.y + b * xv.y + k;
             o.z = a * g.z + b * xv.z + k; o.w = a * g.w + b * xv.w + k;
-            *reinterpret_cast<float4*>(dx + base + s) = o;
+            st4(dx + base + s, o, nt);
         }
     } else if ((S % 4) == 0) {
         for (int s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
@@ -422,10 +451,11 @@ static int check_ncs(int N, int C, int S) {
 static int launch_apply(const float* x, const float* res, float* y, int N, int C, int S, const float* scale,
                         const float* shift, int relu, hipStream_t stream) {
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
-    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
-    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift);
+    const bool nt = bn_stream(N, C, S);
+    if (res && relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift, nt);
+    else if (res) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift, nt);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift, nt);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, stream, x, res, y, C, S, scale, shift, nt);
     return launch_status();
 }
 
@@ -540,22 +570,23 @@ extern "C" int zsv_bn_bwd(const float* dy, const float* x, const float* y, int32
     const dim3 rgrid(C, slices);
     // fuse_relu 1 with a residual gradient: the reduction writes the masked gradient (= d_residual), the apply pass reads it (mode 0)
     const bool g_from_reduce = fuse_relu == 1 && d_residual != nullptr && ZSV_KNOB(BN_NO_MASKED_G) == nullptr;
+    const bool nt = bn_stream(N, C, S);
     if (fuse_relu == 2)
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<2>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr, nt);
     else if (fuse_relu == 1)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part,
-                           g_from_reduce ? d_residual : (float*)nullptr);
+                           g_from_reduce ? d_residual : (float*)nullptr, nt);
     else
-        hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<0>), rgrid, dim3(256), 0, stream, dy, x, y, N, C, S, slices, save_mean, save_invstd, gamma, beta, w.part, (float*)nullptr, nt);
     if ((st = launch_status())) return st;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, stream, (const double*)w.part, C, slices,
                        (double)N * S, gamma, save_mean, save_invstd, dgamma, dbeta, w.scale, w.shift, w.c1, beta, w.c2);
     if ((st = launch_status())) return st;
     const dim3 grid((unsigned)(N * C), (unsigned)((S + ROW_CHUNK - 1) / ROW_CHUNK));
-#define ZSV_BWD_APPLY(R, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, D>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1, gamma, save_invstd, w.c2)
+#define ZSV_BWD_APPLY(R, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, D>), grid, dim3(256), 0, stream, dy, x, y, dx, d_residual, C, S, w.scale, w.shift, w.c1, gamma, save_invstd, w.c2, nt)
     if (g_from_reduce) {
         hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false>), grid, dim3(256), 0, stream, (const float*)d_residual, x, y, dx, (float*)nullptr, C, S, w.scale, w.shift, w.c1,
-                           gamma, save_invstd, w.c2);
+                           gamma, save_invstd, w.c2, nt);
         return launch_status();
     }
     if (fuse_relu == 2) { if (d_residual) ZSV_BWD_APPLY(2, true); else ZSV_BWD_APPLY(2, false); }

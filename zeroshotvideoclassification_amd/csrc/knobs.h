@@ -46,6 +46,7 @@
     X(WINO_NO_SPLITK) \
     X(NO_WINOT) \
     X(WINOT_MIN_TILES) \
+    X(BN_NT_MB) \
     X(BN_NO_MASKED_G) \
     X(WINOT_MAX_WASTE) \
     X(NO_WINO_FWD) \
