@@ -151,6 +151,9 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(IgemmParams prm
 // written as a linear image of the padded [16][LDA] array (pad slots load a dummy element).
 // One chunk is in flight: issued right after the barrier, awaited (vmcnt(0)) before the next one.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef ZSV_TAP_INTERLEAVE
+#define ZSV_TAP_INTERLEAVE 1
+#endif
 #ifndef WAVES_PER_EU
 #define WAVES_PER_EU 4
 #endif
@@ -264,39 +267,42 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     const int c_begin = split * per_split;
     const int nchunks = max(0, min(nchunks_all, c_begin + per_split) - c_begin);
     int ld_cb = c_begin / taps_, ld_tap = c_begin - ld_cb * taps_;
-    auto issue_chunk = [&](int chunk, int buf) {
+    // The DMA instructions of a chunk: BPASS image rows, APASS panel pieces, (PRE, wave 0) the scales / shifts -- NDMA per wave.  In
+    // the chunk loop they go out one at a time between the MFMAs of the chunk before (ZSV_TAP_INTERLEAVE; as conv_wino.hip's F(4,3)
+    // kernels, where the burst at the head of a chunk cost a third of the chunk: profiles/r03_temporal_phase_trace.txt).
+    constexpr int NDMA = BPASS + APASS + (PRE ? 1 : 0);
+    constexpr bool IL = ZSV_TAP_INTERLEAVE && TM * TN <= 16 && !(PRE && TM * TN == 16);     // (the 144-row tiles have no registers to spare: 128-VGPR budget)
+    unsigned ic_voff = 0;
+    int ic_ci0 = 0;
+    auto issue_begin = [&]() {
         const int toff = sgpr(tapoff[ld_tap]);
         const unsigned ok = (vmask >> ld_tap) & 1u;
-        const unsigned voff = (unsigned)(base_bytes + toff) | (ok - 1u);
-        const int ci0 = ld_cb * 16;
-        float* bdst = &Bs[buf][brow0 * LDB + bcol0];
-        if (ci0 + 16 <= prm.gC) {
-#pragma unroll
-            for (int j = 0; j < BPASS; ++j) {
-                const int ci = ci0 + brow0 + RPP * j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t)(bdst + RPP * j * LDB), 4, (int)voff, ci * ch_bytes, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < BPASS; ++j) {
-                const int ci = ci0 + brow0 + RPP * j;
-                const unsigned v = ci < prm.gC ? voff : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t)(bdst + RPP * j * LDB), 4, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < APASS; ++j) {
-            if (64 * (wave + 4 * j) < ASLOTS)          // wave-uniform
-                __builtin_amdgcn_global_load_lds(a_src[j] + (size_t)(c_begin + chunk) * a_chunk_stride,
-                                                 (lds_ptr_t)(&As[buf][256 * (wave + 4 * j)]), 16, 0, 0);
-        }
-        if constexpr (PRE) {
+        ic_voff = (unsigned)(base_bytes + toff) | (ok - 1u);
+        ic_ci0 = ld_cb * 16;
+        if (++ld_tap == taps_) { ld_tap = 0; ++ld_cb; }
+    };
+    auto issue_piece = [&](int chunk, int buf, int j) {
+        if (j < BPASS) {
+            float* bdst = &Bs[buf][brow0 * LDB + bcol0];
+            const int ci = ic_ci0 + brow0 + RPP * j;
+            const unsigned v = ci < prm.gC ? ic_voff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(g_rsrc, (lds_ptr_t)(bdst + RPP * j * LDB), 4, (int)v, ci < prm.gC ? ci * ch_bytes : 0, 0, 0);
+        } else if (j < BPASS + APASS) {
+            const int q = j - BPASS;
+            if (64 * (wave + 4 * q) < ASLOTS)          // wave-uniform
+                __builtin_amdgcn_global_load_lds(a_src[q] + (size_t)(c_begin + chunk) * a_chunk_stride,
+                                                 (lds_ptr_t)(&As[buf][256 * (wave + 4 * q)]), 16, 0, 0);
+        } else if constexpr (PRE) {
             if (wave == 0) {        // lanes 0..3: scale[ci0 .. ci0+15], lanes 4..7: shift[...]; the others read out of range (zeros)
-                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ci0 + 4 * (lane & 3)) : 0xFFFFFFF0u;
+                const unsigned off = lane < 8 ? 4u * (unsigned)((lane >> 2) * prm.pre_pitch + ic_ci0 + 4 * (lane & 3)) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(pre_rsrc, (lds_ptr_t)(&pre_lds[buf * 256]), 16, (int)off, 0, 0, 0);
             }
         }
-        if (++ld_tap == taps_) { ld_tap = 0; ++ld_cb; }
+    };
+    auto issue_chunk = [&](int chunk, int buf) {
+        issue_begin();
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) issue_piece(chunk, buf, j);
     };
 
     f32x4 acc[TM][TN];
@@ -320,7 +326,11 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
     int cur_tap = c_begin - (c_begin / taps_) * taps_;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunks) issue_chunk(ch + 1, cur ^ 1);
+        const bool prefetching = ch + 1 < nchunks;
+        if (prefetching) {
+            if (IL) issue_begin();
+            else issue_chunk(ch + 1, cur ^ 1);
+        }
         const float* as = &As[cur][0];
         const float* bs = &Bs[cur][0];
         float psc[PRE ? BK / 4 : 1], psh[PRE ? BK / 4 : 1];
@@ -365,8 +375,22 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_ & 1][kk][i], b[s_ & 1][kk][j], acc[i][j], 0, 0, 0);
+                        if (IL) {          // one DMA instruction of the next chunk after every EV-th MFMA
+                            constexpr int TOTAL = NS * FK * TM * TN, EV = TOTAL / NDMA > 0 ? TOTAL / NDMA : 1;
+                            const int idx = ((s_ * FK + kk) * TM + i) * TN + j;
+                            if (TOTAL >= NDMA && idx % EV == EV - 1 && idx / EV < NDMA && prefetching) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                issue_piece(ch + 1, cur ^ 1, idx / EV);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+            if (IL && s_ == NS - 1 && NS * FK * TM * TN < NDMA && prefetching) {      // (tiny tiles: the rest in a row)
+#pragma unroll
+                for (int q = 0; q < NDMA; ++q) issue_piece(ch + 1, cur ^ 1, q);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
