@@ -259,6 +259,30 @@ int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H,
 /* [N][S][Cp] bf16 -> (N, C) fp32 mean over the S voxels (resnet.py:251-254 avgpool + flatten). */
 int zsv_meanpool_bf16(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);
 
+/* ---- bf16 TRAINING step: the reference's mixed-precision step (main.py:172 `with autocast():`, main.py:137,195-203
+ * GradScaler) on channels-last bf16 activations [R = N*T*H*W][Cp] (the layout of the bf16 convolution above).  Under
+ * autocast aten::batch_norm keeps fp32 statistics / affine parameters on a reduced-precision input and writes the reduced
+ * precision; `out += residual; relu` (resnet.py:110-111) are element-wise passes in it.
+ * zsv_bn_cl_fwd_train: train-mode BatchNorm3d (resnet.py:42,50,96,97,184,272) of the raw convolution output z: batch
+ *   statistics (fp32 / fp64 accumulation), running statistics updated as torch does (unbiased variance, `momentum`),
+ *   y = relu?(gamma*(z-mean)*invstd + beta (+ residual)) rounded once to bf16; save_mean / save_invstd (C floats) for backward.
+ * zsv_bn_cl_bwd: g = dy * (y > 0) when relu_mask (y = the forward's output), dgamma / dbeta (C floats, may be NULL),
+ *   dz (bf16) = the BatchNorm input gradient; g_out (may be NULL) receives g itself -- the gradient of a residual branch.
+ * workspace: zsv_bn_cl_workspace_bytes(R, C) bytes (0 = unsupported shape). */
+size_t zsv_bn_cl_workspace_bytes(int64_t R, int32_t C);
+int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
+                        float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
+int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
+                  const float* save_invstd, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* layout converters between the two activation layouts: [N][S][Cp] bf16 <-> (N, C, S) fp32 (C > 4; pad channels read as /
+ * written with zero): they hand a bf16 tensor to the fp32 NCDHW kernels (weight gradients of the mixed-precision step). */
+int zsv_cl_bf16_to_ncs_f32(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);
+int zsv_ncs_f32_to_cl_bf16(const float* x, int32_t N, int32_t S, int32_t C, void* out, void* stream);
+/* gradient of zsv_meanpool_bf16 (network.py:595 under autocast): dx[n][s][c] = dpooled[n][c] / S in bf16 */
+int zsv_meanpool_bf16_bwd(const float* dpooled, int32_t N, int32_t S, int32_t C, void* dx, void* stream);
+
 /* ---- clip pre-processing ------------------------------------------------------ */
 /* The reference's transform chain (auxiliary/transforms.py:41-56): (u8/255 - 1)/2 and THWC->CTHW
  * (:116-117), bilinear resize of the short side to 128 with align_corners=False (:99-107), a

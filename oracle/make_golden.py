@@ -386,13 +386,78 @@ def run_t32_batch():
             "meta_seed": np.array(199), "meta_bn_jitter": np.array(True), "meta_network": np.array("r2plus1d_18")}
 
 
+# ---------------------------------------------------------------------------------------------
+# the reference's mixed-precision step (main.py:172 `with autocast():`, main.py:137,195-203 GradScaler) in bf16
+AUTOCAST_CASE = dict(network="r2plus1d_18", n=3, frames=8, size=56, bn_jitter=True, steps=30, lr=1e-3)
+
+
+def run_autocast_bf16():
+    """The imported reference under ``torch.autocast("cpu", dtype=torch.bfloat16)`` -- main.py:170-203's forward and loss
+    inside the context, backward outside -- on the ``r2plus1d_small`` inputs: embeddings, loss, per-parameter gradient norms
+    and samples of the first step, BatchNorm running statistics after it, and the loss of 30 Adam steps (with the fp32
+    curve of the same steps next to it).  ``amp.autocast`` + ``amp`` training path are checked against these."""
+    c = AUTOCAST_CASE
+    ref_network, _ = import_reference()
+    opt = R.make_opt(c["network"])
+    torch.manual_seed(0)
+    ref = ref_network.get_network(opt)
+    weights = S.keyed_state_dict(ref.state_dict(), seed=0, bn_jitter=c["bn_jitter"])
+    x = S.synthetic_clips(c["n"], c["frames"], c["size"])
+    _, z = S.synthetic_targets(c["n"])
+    out = {}
+
+    def step(model, optim, autocast):
+        optim.zero_grad()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            y = R.embed(model, x)
+            loss = F.mse_loss(y, z)                      # (autocast runs mse_loss in fp32)
+        loss.backward()
+        optim.step()
+        return y, loss
+
+    ref.load_state_dict(weights)
+    ref.train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = R.embed(ref, x)
+        loss = F.mse_loss(y, z)
+    loss.backward()
+    out["emb"] = y.detach().float().numpy()
+    out["emb_dtype"] = np.array(str(y.dtype))
+    out["loss"] = np.float64(loss.item())
+    names, norms, samples = [], [], []
+    for k, p in ref.named_parameters():
+        if p.grad is None:
+            continue
+        assert p.grad.dtype == torch.float32, k        # parameters and their gradients stay fp32 under autocast
+        g = p.grad.flatten()
+        names.append(k)
+        norms.append(g.double().norm().item())
+        smp = np.zeros(16)
+        idx = sample_idx(g.numel(), 16)
+        smp[:len(idx)] = g[idx].numpy()
+        samples.append(smp)
+    out["grad_names"], out["grad_norm"], out["grad_sample"] = np.array(names), np.array(norms), np.stack(samples)
+    sd = ref.state_dict()
+    out["running_mean_after1"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_mean")])
+    out["running_var_after1"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_var")])
+    for tag, autocast in (("bf16", True), ("f32", False)):
+        ref.load_state_dict(weights)
+        ref.train()
+        optim = torch.optim.Adam(ref.parameters(), lr=c["lr"])
+        out[f"loss_curve_{tag}"] = np.array([step(ref, optim, autocast)[1].item() for _ in range(c["steps"])])
+    for k, v in c.items():
+        out["meta_" + k] = np.array(v)
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     ref_network, _ = import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("transforms", run_transforms), ("transforms_t4", run_transforms_t4), ("accuracy", run_accuracy),
-                     ("surface_extras", run_surface_extras), ("r2plus1d_t32_batch", run_t32_batch)):
+                     ("surface_extras", run_surface_extras), ("r2plus1d_t32_batch", run_t32_batch),
+                     ("r2plus1d_small_autocast_bf16", run_autocast_bf16)):
         if only and name not in only:
             continue
         t0 = time.time()

@@ -28,14 +28,14 @@ def golden_dir():
     return GOLDEN
 
 
-# The library snapshots its ZSV_* switches (csrc/knobs.h); `_lib.load()` refreshes the snapshot after an os.environ write.
-# Tests that hold on to the ctypes handle and call the raw C ABI after `monkeypatch.setenv("ZSV_...")` never pass through
-# `load()` again, so the two monkeypatch methods do it for them, and every test starts from a fresh snapshot.
+# The library snapshots its ZSV_* switches (csrc/knobs.h); `_lib.reload_knobs()` refreshes the snapshot after an os.environ
+# write.  The two monkeypatch methods call it, and every test starts from a fresh snapshot (monkeypatch's undo does not pass
+# through them).
 def _refresh_knobs():
     try:
         from zeroshotvideoclassification_amd import _lib
         if os.path.isfile(_lib.LIB_PATH):
-            _lib.load()
+            _lib.reload_knobs()
     except Exception:
         pass
 

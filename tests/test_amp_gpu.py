@@ -1,0 +1,277 @@
+"""The bf16 training path (``zeroshotvideoclassification_amd.amp``): the reference's mixed-precision step, main.py:172
+``with autocast():`` + main.py:137,195-203 ``GradScaler``.
+
+Bars (bf16 has 8 significand bits; two different bf16 implementations of a 37-convolution trunk differ from each other by as
+much as each differs from fp32, so the fixture of the imported reference under ``torch.autocast("cpu", dtype=bfloat16)`` is a
+statistical oracle, not a bit oracle):
+* element-wise / reduction kernels (BatchNorm forward + backward on channels-last bf16): against the same arithmetic in fp64 on the
+  same bf16-rounded inputs, 2^-7 relative of the output range (one rounding to bf16), statistics / parameter gradients 1e-4;
+* convolution input gradient (forward kernel on flipped / transposed weights, zero-interleaved for strides): 2^-7 of the output
+  range against torch CPU fp64 on the bf16-rounded operands;
+* embeddings: cosine >= 0.99 per row and 4e-2 absolute against BOTH the autocast fixture and the fp32 fixture; loss within 3 %;
+* gradients of the first step: per-parameter cosine against the fp32 HIP path >= 0.9 for every parameter, median >= 0.995; norms
+  within 15 % of the autocast fixture's for the parameters that carry 99 % of the gradient energy;
+* 30 Adam steps: the loss falls like the autocast oracle's curve (every step within 25 %, the last five within 15 %).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import load_golden, make_opt  # noqa: E402
+from zeroshotvideoclassification_amd import amp, inference, network, ops, optim, synthetic, train  # noqa: E402
+
+DEV = "cuda"
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_cl(x):
+    """(N, C, T, H, W) fp32 -> channels-last bf16 with the channel pitch of the bf16 kernels."""
+    return amp.ncdhw_to_cl_bf16(x.to(DEV).float())
+
+
+def from_cl(x, c):
+    return amp.cl_to_ncdhw_f32(x, c).cpu()
+
+
+@pytest.mark.parametrize("shape", [(2, 45, 4, 9, 7), (3, 64, 2, 8, 8), (1, 144, 3, 5, 6), (2, 921, 1, 3, 3), (1, 32, 1, 1, 70)])
+def test_layout_converters_round_trip(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    cl = to_cl(x)
+    n, c, t, h, w = shape
+    cp = inference.channel_pitch(c)
+    assert tuple(cl.shape) == (n, t, h, w, cp) and cl.dtype == torch.bfloat16
+    assert torch.equal(cl[..., :c].float().cpu(), bf16_round(x).permute(0, 2, 3, 4, 1))      # round-to-nearest-even, same as torch
+    assert float(cl[..., c:].float().abs().sum()) == 0.0                                       # pad channels are zero
+    assert torch.equal(from_cl(cl, c), bf16_round(x))
+
+
+@pytest.mark.parametrize("shape,relu,res", [((2, 45, 4, 9, 7), True, False), ((3, 64, 2, 8, 8), True, True),
+                                            ((1, 144, 3, 5, 6), False, False), ((2, 230, 2, 4, 4), False, True),
+                                            ((2, 1152, 1, 3, 3), True, True), ((4, 64, 8, 28, 28), True, True)])
+def test_batchnorm_channels_last_forward_backward(shape, relu, res):
+    n, c, t, h, w = shape
+    g = torch.Generator().manual_seed(c * 7 + t)
+    z = bf16_round(torch.randn(shape, generator=g) * 1.5 + 0.3)
+    r = bf16_round(torch.randn(shape, generator=g)) if res else None
+    dy = bf16_round(torch.randn(shape, generator=g))
+    bn = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+    ref = torch.nn.BatchNorm3d(c).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    ref.train()
+    z64 = z.double().requires_grad_(True)
+    pre = ref(z64) + (r.double() if res else 0.0)
+    y64 = torch.relu(pre) if relu else pre
+    # the kernel rounds y to bf16 and masks on the ROUNDED output (y > 0); a value that rounds to zero is masked: same set almost surely
+    y64.backward(dy.double())
+
+    bn = bn.to(DEV).train()
+    z_cl, r_cl, dy_cl = to_cl(z), (to_cl(r) if res else None), to_cl(dy)
+    y_cl, mean, invstd = amp.bn_cl_fwd_train(z_cl, bn, r_cl, relu)
+    dz_cl, g_cl, dgamma, dbeta = amp.bn_cl_bwd(dy_cl, y_cl, z_cl, bn, mean, invstd, relu, want_g=res)
+    torch.cuda.synchronize()
+    y = from_cl(y_cl, c)
+    scale = float(y64.abs().max())
+    assert float((y.double() - y64.detach()).abs().max()) <= scale * 2.0 ** -7
+    assert float(y_cl[..., c:].float().abs().sum()) == 0.0
+    m64 = z.double().mean(dim=(0, 2, 3, 4))
+    v64 = z.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert float((mean.cpu().double() - m64).abs().max()) < 1e-5
+    assert float((invstd.cpu().double() * torch.sqrt(v64 + bn.eps) - 1).abs().max()) < 1e-5
+    assert float((bn.running_mean.cpu().double() - ref.running_mean).abs().max()) < 1e-5
+    assert float((bn.running_var.cpu().double() / ref.running_var - 1).abs().max()) < 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    dz = from_cl(dz_cl, c)
+    gscale = float(z64.grad.abs().max())
+    assert float((dz.double() - z64.grad).abs().max()) <= gscale * 2.0 ** -6
+    assert float((dgamma.cpu().double() - ref.weight.grad).abs().max()) <= 2e-3 * float(ref.weight.grad.abs().max()) + 1e-6
+    assert float((dbeta.cpu().double() - ref.bias.grad).abs().max()) <= 2e-3 * float(ref.bias.grad.abs().max()) + 1e-6
+    if res:
+        gm = from_cl(g_cl, c)
+        expect = dy * (y > 0) if relu else dy
+        assert torch.equal(gm, expect)
+
+
+@pytest.mark.parametrize("geom", [
+    # (N, Cin, T, H, W), (Cout, kernel), stride, padding
+    ((2, 64, 4, 12, 12), (144, (1, 3, 3)), (1, 1, 1), (0, 1, 1)),      # spatial half of a (2+1)D pair
+    ((2, 144, 4, 12, 12), (64, (3, 1, 1)), (1, 1, 1), (1, 0, 0)),      # temporal half
+    ((2, 64, 4, 12, 12), (230, (1, 3, 3)), (1, 2, 2), (0, 1, 1)),      # strided spatial (layer2 entry)
+    ((2, 230, 4, 6, 6), (128, (3, 1, 1)), (2, 1, 1), (1, 0, 0)),       # strided temporal
+    ((2, 64, 4, 12, 12), (128, (1, 1, 1)), (2, 2, 2), (0, 0, 0)),      # strided 1x1x1 shortcut
+    ((1, 64, 4, 10, 10), (64, (3, 3, 3)), (1, 1, 1), (1, 1, 1)),       # R3D-18
+    ((1, 64, 4, 10, 10), (128, (3, 3, 3)), (2, 2, 2), (1, 1, 1)),      # R3D-18 strided
+    ((1, 64, 3, 7, 9), (96, (1, 3, 3)), (1, 2, 2), (0, 1, 1)),         # odd extents: the remainder rows / columns get zero gradient
+])
+def test_input_gradient_through_the_forward_kernel(geom):
+    xs, (cout, k), stride, pad = geom
+    n, cin, t, h, w = xs
+    g = torch.Generator().manual_seed(cout + cin)
+    conv = torch.nn.Conv3d(cin, cout, k, stride=stride, padding=pad, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(bf16_round(torch.randn(conv.weight.shape, generator=g) * (cin * k[0] * k[1] * k[2]) ** -0.5))
+    x64 = torch.zeros(xs, dtype=torch.float64, requires_grad=True)
+    y64 = F.conv3d(x64, conv.weight.double(), None, stride, pad)
+    dz = bf16_round(torch.randn(y64.shape, generator=g))
+    y64.backward(dz.double())
+    u = amp._Unit(conv.to(DEV), torch.nn.BatchNorm3d(cout).to(DEV), False)
+    rec = amp._Record()
+    rec.unit, rec.desc = u, u.desc(n, t, h, w)
+    dx_cl = amp.Bf16TrainPath._dgrad(rec, to_cl(dz))
+    torch.cuda.synchronize()
+    dx = from_cl(dx_cl, cin)
+    assert tuple(dx.shape) == tuple(xs)
+    scale = float(x64.grad.abs().max())
+    assert float((dx.double() - x64.grad).abs().max()) <= scale * 2.0 ** -7
+
+
+def _model(net="r2plus1d_18", jitter=True):
+    model = network.get_network(make_opt(net))
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=jitter)
+    model.load_state_dict(weights)
+    return model.to(DEV), weights
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_autocast_training_step_against_the_reference_under_cpu_autocast():
+    g = load_golden("r2plus1d_small_autocast_bf16")
+    g32 = load_golden("r2plus1d_small")
+    model, weights = _model()
+    n, frames, size = int(g["meta_n"]), int(g["meta_frames"]), int(g["meta_size"])
+    x = synthetic.synthetic_clips(n, frames, size).to(DEV)
+    _, z = synthetic.synthetic_targets(n)
+    z = z.to(DEV)
+    model.train()
+    # fp32 HIP path first (gradients to compare directions with)
+    model.zero_grad(set_to_none=True)
+    F.mse_loss(train.embed(model, x), z).backward()
+    ops.join_wgrad_streams()
+    grads32 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.load_state_dict(weights)
+    model.zero_grad(set_to_none=True)
+    with amp.autocast():
+        y = train.embed(model, x)
+        loss = F.mse_loss(y, z)
+    assert y.dtype == torch.float32                       # the head runs in fp32 (the reference's autocast output is bf16)
+    loss.backward()
+    ops.join_wgrad_streams()
+    torch.cuda.synchronize()
+    for name, ref in (("autocast oracle", g["emb"]), ("fp32 oracle", g32["emb_f32"])):
+        ref = torch.from_numpy(np.asarray(ref, dtype=np.float32))
+        for row in range(n):
+            assert _cos(y[row].cpu(), ref[row]) >= 0.99, (name, row)
+        assert float((y.cpu() - ref).abs().max()) <= 4e-2, name
+    assert abs(loss.item() - float(g["loss"])) <= 0.03 * float(g["loss"])
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert sorted(grads) == sorted(str(k) for k in g["grad_names"]) == sorted(grads32)
+    for k, v in grads.items():
+        assert v.dtype == torch.float32 and torch.isfinite(v).all(), k
+    cosines = sorted((_cos(grads[k], grads32[k]), k) for k in grads)
+    assert cosines[0][0] >= 0.9, cosines[:5]
+    assert cosines[len(cosines) // 2][0] >= 0.995
+    ref_norm = {str(k): float(v) for k, v in zip(g["grad_names"], g["grad_norm"])}
+    energy = sorted(ref_norm.items(), key=lambda kv: -kv[1])
+    total = sum(v * v for _, v in energy)
+    acc = 0.0
+    for k, v in energy:
+        assert abs(float(grads[k].double().norm()) - v) <= 0.15 * v, (k, float(grads[k].norm()), v)
+        acc += v * v
+        if acc >= 0.99 * total:
+            break
+    # BatchNorm running statistics after the step
+    sd = model.state_dict()
+    rm = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_mean")]).cpu().numpy()
+    rv = torch.cat([sd[k].flatten() for k in sd if k.endswith("running_var")]).cpu().numpy()
+    assert np.abs(rm - g["running_mean_after1"]).max() <= 2e-2 * max(1.0, np.abs(g["running_mean_after1"]).max())
+    assert np.abs(rv / g["running_var_after1"] - 1).max() <= 5e-2
+
+
+def test_thirty_adam_steps_track_the_autocast_oracle_loss_curve():
+    g = load_golden("r2plus1d_small_autocast_bf16")
+    model, _ = _model()
+    n, frames, size = int(g["meta_n"]), int(g["meta_frames"]), int(g["meta_size"])
+    x = synthetic.synthetic_clips(n, frames, size).to(DEV)
+    _, z = synthetic.synthetic_targets(n)
+    z = z.to(DEV)
+    model.train()
+    opt = optim.FusedAdam(model.parameters(), lr=float(g["meta_lr"]))      # main.py:131 Adam, driven by the scaler (main.py:137,195-203)
+    scaler = optim.LossScaler(init_scale=2.0 ** 10)
+    crit = torch.nn.MSELoss()
+    losses = []
+    for _ in range(int(g["meta_steps"])):
+        _, loss = train.train_step(model, opt, crit, x, z, scaler=scaler, autocast=True)
+        losses.append(loss)
+    torch.cuda.synchronize()
+    got = torch.stack(losses).cpu().double().numpy()
+    want = np.asarray(g["loss_curve_bf16"], dtype=np.float64)
+    assert np.all(np.isfinite(got))
+    assert np.abs(got / want - 1).max() <= 0.25, (got, want)
+    assert np.abs(got[-5:] / want[-5:] - 1).max() <= 0.15
+    assert got[-1] < 0.01 * got[0]                                       # it really trains
+
+
+@pytest.mark.parametrize("net", ["r3d_18", "mc3_18"])
+def test_autocast_on_the_other_trunks_agrees_with_the_fp32_path(net):
+    model, weights = _model(net)
+    x = synthetic.synthetic_clips(2, 8, 56).to(DEV)
+    _, z = synthetic.synthetic_targets(2)
+    z = z.to(DEV)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    y32 = train.embed(model, x)
+    F.mse_loss(y32, z).backward()
+    ops.join_wgrad_streams()
+    grads32 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.load_state_dict(weights)
+    model.zero_grad(set_to_none=True)
+    with amp.autocast():
+        y = train.embed(model, x)
+    F.mse_loss(y, z).backward()
+    ops.join_wgrad_streams()
+    torch.cuda.synchronize()
+    for row in range(2):
+        assert _cos(y[row], y32[row]) >= 0.99
+    cosines = sorted(_cos(p.grad, grads32[k]) for k, p in model.named_parameters() if p.grad is not None)
+    assert cosines[0] >= 0.85 and cosines[len(cosines) // 2] >= 0.99
+
+
+def test_autocast_surface():
+    """Outside the context nothing changes; inside it eval mode runs the bf16 inference engine; a frozen trunk gets no tape;
+    fp16 is refused; CPU tensors are refused (no fallback)."""
+    model, _ = _model()
+    x = synthetic.synthetic_clips(2, 8, 56).to(DEV)
+    model.train()
+    assert not amp.is_autocast_enabled()
+    with amp.autocast():
+        assert amp.is_autocast_enabled()
+        with amp.autocast(enabled=False):
+            assert not amp.is_autocast_enabled()
+        assert amp.is_autocast_enabled()
+    assert not amp.is_autocast_enabled()
+    with pytest.raises(RuntimeError):
+        amp.autocast(dtype=torch.float16)
+    model.eval()
+    with torch.no_grad():
+        y_eval32, _ = model(x)
+        with amp.autocast():
+            y_eval16, none = model(x)
+    assert none is None
+    for row in range(2):
+        assert _cos(y_eval16[row], y_eval32[row]) >= 0.995
+    with pytest.raises(RuntimeError):
+        amp.trunk_features(model.model, x.reshape(2, 3, 8, 56, 56).cpu())

@@ -10,6 +10,8 @@ within 2e-2 (max abs, components are O(0.06)) and cosine >= 0.999 of the fp32 or
 """
 import numpy as np
 import pytest
+import zlib
+
 import torch
 import torch.nn.functional as F
 
@@ -57,7 +59,7 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
 def test_conv_bf16_matches_fp64_of_rounded_operands(case):
     n, cin, cout, (t, h, w), k, s, p, use_res, relu = case
-    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))   # (not hash(): randomised per process)
     x = bf16_round(torch.randn((n, cin, t, h, w), generator=g))
     wgt = torch.randn((cout, cin) + k, generator=g) / np.sqrt(cin * np.prod(k))
     scale = torch.rand(cout, generator=g) + 0.5

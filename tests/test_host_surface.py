@@ -207,32 +207,40 @@ def test_bench_self_launch_builds_one_child_per_gpu():
 
 
 def test_environment_switches_are_snapshotted_and_reloaded():
-    """The library reads its ZSV_* switches once (csrc/knobs.h), not with getenv() on every launch; flipping one through
-    os.environ in a live process is noticed by _lib's audit hook and re-read before the next call."""
+    """The library reads its ZSV_* switches once (csrc/knobs.h), not with getenv() on every launch; a process that flips one
+    calls _lib.reload_knobs(), which re-reads them (and tells the weight-panel cache) only when something changed.  No audit
+    hook is installed unless ZSV_WATCH_ENV asks for it."""
     from ctypes import byref
     from zeroshotvideoclassification_amd import _lib, ops
     d = ops.conv_desc((2, 64, 8, 56, 56), (144, 64, 1, 3, 3), 1, (0, 1, 1))
     saved = os.environ.pop("ZSV_NO_WINO", None)
     try:
         lib = _lib.load()
+        _lib.reload_knobs()
         base = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
+        gen = _lib.knob_generation()
         os.environ["ZSV_NO_WINO"] = "1"
-        assert _lib._knobs_dirty
         assert lib.zsv_conv3d_fwd_workspace_bytes(byref(d)) == base          # the snapshot, not the environment, decides
-        lib = _lib.load()                                   # every op passes through load(): the snapshot is refreshed here
-        assert not _lib._knobs_dirty
+        assert _lib.load().zsv_conv3d_fwd_workspace_bytes(byref(d)) == base  # ... and load() alone does not look either
+        assert _lib.reload_knobs() is True
+        assert _lib.knob_generation() == gen + 1
         direct = lib.zsv_conv3d_fwd_workspace_bytes(byref(d))
         assert direct != base                               # the Winograd-form kernel and the direct kernel pack weights differently
+        assert _lib.reload_knobs() is False                 # nothing changed: cached panels stay valid
+        assert _lib.knob_generation() == gen + 1
         del os.environ["ZSV_NO_WINO"]
-        assert _lib.load().zsv_conv3d_fwd_workspace_bytes(byref(d)) == base
+        _lib.reload_knobs()
+        assert lib.zsv_conv3d_fwd_workspace_bytes(byref(d)) == base
         os.environ["UNRELATED_VARIABLE"] = "1"
-        assert not _lib._knobs_dirty
+        assert _lib.reload_knobs() is False
         del os.environ["UNRELATED_VARIABLE"]
     finally:
         os.environ.pop("ZSV_NO_WINO", None)
         if saved is not None:
             os.environ["ZSV_NO_WINO"] = saved
-        _lib.load()
+        _lib.reload_knobs()
+    lib_src = open(os.path.join(ROOT, "zeroshotvideoclassification_amd", "_lib.py")).read()
+    assert lib_src.count("sys.addaudithook(") == 1 and 'os.environ.get("ZSV_WATCH_ENV")' in lib_src   # opt-in only
     csrc = os.path.join(ROOT, "zeroshotvideoclassification_amd", "csrc")
     src = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith(".hip") and f != "knobs.hip")
     assert "getenv(" not in src                         # the launch path never walks the environment

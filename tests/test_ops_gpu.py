@@ -5,6 +5,8 @@ max|err| <= 2e-5 * max|ref| (+ tiny abs), far inside the 1e-3 bar north_star sta
 """
 import numpy as np
 import pytest
+import zlib
+
 import torch
 import torch.nn.functional as F
 
@@ -62,7 +64,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv3d_fwd_dgrad_wgrad(case):
     name, n, cin, t, h, w, cout, k, s, p, has_bias = case
-    g = torch.Generator().manual_seed(hash(name) % 2**31)
+    g = torch.Generator().manual_seed(zlib.crc32(str(name).encode()))    # (not hash(): randomised per process, a failure could not be replayed)
     x = torch.randn(n, cin, t, h, w, generator=g)
     wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
     b = torch.randn(cout, generator=g) if has_bias else None
@@ -457,7 +459,7 @@ WGRAD_DMA_CASES = [
 @pytest.mark.parametrize("case", WGRAD_DMA_CASES, ids=[c[0] for c in WGRAD_DMA_CASES])
 def test_conv3d_wgrad_dma_path(case, monkeypatch):
     name, n, cin, (t, h, w), cout, k, p = case
-    g = torch.Generator().manual_seed(hash(name) % 2**31)
+    g = torch.Generator().manual_seed(zlib.crc32(str(name).encode()))    # (not hash(): randomised per process, a failure could not be replayed)
     x = torch.randn(n, cin, t, h, w, generator=g)
     wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * np.prod(k))
     xr, wr = x.double(), wt.double().requires_grad_()

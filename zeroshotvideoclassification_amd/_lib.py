@@ -80,6 +80,12 @@ SIGNATURES = {
     "zsv_conv3d_bf16_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P]),
     "zsv_clip_to_bf16": (c_int, [_P] + [c_int32] * 9 + [_P, _P]),
     "zsv_meanpool_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "zsv_bn_cl_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "zsv_bn_cl_fwd_train": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_bn_cl_bwd": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_cl_bf16_to_ncs_f32": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "zsv_ncs_f32_to_cl_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
+    "zsv_meanpool_bf16_bwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_clip_transform": (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_int32, _P, _P, _P]),
     "zsv_cosine_topk_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "zsv_cosine_topk": (c_int, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_size_t, _P]),
@@ -108,14 +114,38 @@ _lock = threading.Lock()
 _lib = None
 
 
-# The library snapshots its ZSV_* switches at load (csrc/knobs.h).  Tests and A/B tools flip them with os.environ inside
-# a live process: an audit hook notices such a write and the next ``load()`` -- every op goes through it -- re-reads them.
+# The library snapshots its ZSV_* switches at load (csrc/knobs.h): the launch path reads an array, never getenv().  A process that
+# flips a switch afterwards (tests, A/B tools) calls ``reload_knobs()``.  (Round 3 watched os.environ with a process-wide audit
+# hook instead -- a Python callback on every audited event of the interpreter, on the launch path of every op, that can never be
+# removed; ADVICE r3.  It is now installed only on request, ZSV_WATCH_ENV=1, for interactive sessions.)
 _knobs_dirty = False
-_knob_generation = 0          # bumped whenever the library re-read its switches (cached weight panels depend on them)
+_knob_generation = 0          # bumped whenever the library re-read changed switches (cached weight panels depend on them)
+_knob_snapshot = None
 
 
 def knob_generation() -> int:
     return _knob_generation
+
+
+def _zsv_environment():
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("ZSV_")))
+
+
+def reload_knobs() -> bool:
+    """Make the library re-read its ZSV_* switches if any of them changed since the last snapshot.  Call it after writing a
+    ``ZSV_*`` variable in a live process and before the next launch; not meant to race with launches on other threads.
+    Returns True when something had changed."""
+    global _knob_generation, _knob_snapshot, _knobs_dirty
+    lib = load()
+    with _lock:
+        now = _zsv_environment()
+        _knobs_dirty = False
+        if now == _knob_snapshot:
+            return False
+        _knob_snapshot = now
+        _knob_generation += 1
+        lib.zsv_reload_knobs()
+        return True
 
 
 def _watch_environment(event, args):
@@ -126,14 +156,10 @@ def _watch_environment(event, args):
 
 def load() -> ctypes.CDLL:
     """Load (once) and type the library; raises ``RuntimeError`` when it has not been built."""
-    global _lib, _knobs_dirty, _knob_generation
+    global _lib, _knob_snapshot
     if _lib is not None:
-        if _knobs_dirty:
-            with _lock:
-                if _knobs_dirty:
-                    _knobs_dirty = False
-                    _knob_generation += 1
-                    _lib.zsv_reload_knobs()
+        if _knobs_dirty:                      # (only ever set under ZSV_WATCH_ENV=1)
+            reload_knobs()
         return _lib
     with _lock:
         if _lib is None:
@@ -147,9 +173,10 @@ def load() -> ctypes.CDLL:
                 fn = getattr(lib, name)      # AttributeError if the symbol is not exported
                 fn.restype = res
                 fn.argtypes = args
-            import sys
-            sys.addaudithook(_watch_environment)
-            _knobs_dirty = False
+            if os.environ.get("ZSV_WATCH_ENV"):
+                import sys
+                sys.addaudithook(_watch_environment)
+            _knob_snapshot = _zsv_environment()
             _lib = lib
     return _lib
 

@@ -1,0 +1,374 @@
+"""Mixed-precision (bf16) TRAINING forward / backward of the VideoResNet trunks -- the reference's
+``with autocast(): Y, _ = model(X)`` (main.py:172) with ``GradScaler`` around it (main.py:137,195-203).
+
+    with amp.autocast():                         # torch.cuda.amp.autocast's place in main.py:172
+        y, _ = model(x)                          # network.Model over r2plus1d_18 / r3d_18 / mc3_18
+    loss = criterion(y, z)
+    scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()      # optim.LossScaler
+
+What autocast does to the reference's trunk, restated for this chip: every ``Conv3d`` multiplies reduced-precision
+operands and accumulates in fp32; ``BatchNorm3d`` keeps fp32 statistics and affine parameters on a reduced-precision
+input; ReLU / ``out += residual`` are reduced-precision element-wise passes; parameters and their gradients stay fp32;
+``MSELoss`` runs in fp32.  Here the reduced precision is bf16 (the MI355X matrix core's native 16-bit type; no loss
+scaling is needed for its exponent range, the scaler is supported all the same):
+
+* activations travel channels-last bf16 ``[N][T][H][W][Cp]`` (``csrc/conv_bf16.hip``'s layout);
+* forward convolution: ``zsv_conv3d_bf16_fwd`` (v_mfma_f32_16x16x32_bf16, fp32 accumulation) on the fp32 master weights
+  packed to bf16 once per step; train-mode BatchNorm + ReLU + residual: ``zsv_bn_cl_fwd_train`` (csrc/train_bf16.hip);
+* input gradient: the same convolution kernel on the transposed, tap-flipped weights (a strided convolution's gradient is
+  the stride-1 convolution of the zero-interleaved output gradient); BatchNorm / ReLU backward: ``zsv_bn_cl_bwd``;
+* weight gradient: fp32 accumulation of bf16-rounded operands.  This first slice converts the two operands to the fp32
+  NCDHW layout (``zsv_cl_bf16_to_ncs_f32``) and runs the fp32 weight-gradient kernels of the main path;
+* the pooled 512-d feature, the MLP head, normalisation and the loss stay fp32 (``ops``), as under autocast's fp32 list.
+
+The whole trunk is ONE ``torch.autograd.Function`` (its forward keeps its own tape): autograd sees
+``pooled = f(clips, *trunk parameters)``.  Eval mode under ``autocast`` runs ``inference.Bf16Engine``.
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import threading
+from ctypes import byref, c_void_p
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from ._lib import ConvDesc
+from .inference import _conv_bn_relu_chain, channel_pitch, clip_to_bf16, conv_bf16, meanpool_bf16, pack_conv
+
+_state = threading.local()
+
+
+class autocast:
+    """``torch.cuda.amp.autocast``'s role at main.py:172 for this package's models: inside the context a training-mode
+    ``network.Model`` over a VideoResNet trunk runs its trunk in bf16 (this module); in eval mode it runs the bf16 inference
+    engine.  ``dtype`` must be ``torch.bfloat16`` (fp16 is not implemented: bf16 is the native 16-bit type here)."""
+
+    def __init__(self, enabled: bool = True, dtype: torch.dtype = torch.bfloat16):
+        if enabled and dtype != torch.bfloat16:
+            raise RuntimeError(f"amp.autocast: dtype {dtype} is not supported (bf16 only)")
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = getattr(_state, "enabled", False)
+        _state.enabled = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _state.enabled = self.prev
+        return False
+
+
+def is_autocast_enabled() -> bool:
+    return getattr(_state, "enabled", False)
+
+
+# ---- channels-last bf16 primitives -----------------------------------------------------------------------------------
+def _rows(t: torch.Tensor) -> int:
+    return t.numel() // t.shape[-1]
+
+
+def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torch.Tensor], relu: bool):
+    """Train-mode ``BatchNorm3d`` (+ residual) (+ ReLU) on a channels-last bf16 tensor.  Returns (y, mean, invstd)."""
+    lib = _lib.load()
+    c = bn.num_features
+    r = _rows(z)
+    nbytes = lib.zsv_bn_cl_workspace_bytes(r, c)
+    if nbytes == 0:
+        raise RuntimeError(f"zsv_bn_cl: unsupported shape rows={r} channels={c}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+    y = torch.empty_like(z)
+    mean = torch.empty(c, dtype=torch.float32, device=z.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=z.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+    _lib.check(lib.zsv_bn_cl_fwd_train(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
+                                       bn.running_mean.data_ptr() if track else None,
+                                       bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
+                                       1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
+                                       ops._stream()), "zsv_bn_cl_fwd_train")
+    if track:
+        bn.num_batches_tracked.add_(1)
+    return y, mean, invstd
+
+
+def bn_cl_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], z: torch.Tensor, bn: nn.BatchNorm3d, mean, invstd, relu: bool,
+              want_g: bool):
+    """Returns (dz, g or None, dgamma, dbeta)."""
+    lib = _lib.load()
+    c = bn.num_features
+    r = _rows(z)
+    nbytes = lib.zsv_bn_cl_workspace_bytes(r, c)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+    dz = torch.empty_like(z)
+    g = torch.empty_like(z) if want_g else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
+    _lib.check(lib.zsv_bn_cl_bwd(dy.data_ptr(), ops._ptr(y) if relu else None, z.data_ptr(), r, c, ops._ptr(bn.weight),
+                                 mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, dz.data_ptr(), ops._ptr(g),
+                                 dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, ops._stream()), "zsv_bn_cl_bwd")
+    return dz, g, dgamma, dbeta
+
+
+def cl_to_ncdhw_f32(x: torch.Tensor, channels: int) -> torch.Tensor:
+    """[N][T][H][W][Cp] bf16 -> (N, channels, T, H, W) fp32."""
+    n, t, h, w, _ = x.shape
+    out = torch.empty((n, channels, t, h, w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().zsv_cl_bf16_to_ncs_f32(x.data_ptr(), n, t * h * w, channels, out.data_ptr(), ops._stream()),
+               "zsv_cl_bf16_to_ncs_f32")
+    return out
+
+
+def ncdhw_to_cl_bf16(x: torch.Tensor) -> torch.Tensor:
+    """(N, C, T, H, W) fp32 -> [N][T][H][W][Cp] bf16 (pad channels zero)."""
+    ops._require(x)
+    x = x.contiguous()
+    n, c, t, h, w = x.shape
+    out = torch.empty((n, t, h, w, channel_pitch(c)), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().zsv_ncs_f32_to_cl_bf16(x.data_ptr(), n, t * h * w, c, out.data_ptr(), ops._stream()),
+               "zsv_ncs_f32_to_cl_bf16")
+    return out
+
+
+def meanpool_bf16_bwd(dpooled: torch.Tensor, like: torch.Tensor, channels: int) -> torch.Tensor:
+    n, t, h, w, _ = like.shape
+    dx = torch.empty_like(like)
+    _lib.check(_lib.load().zsv_meanpool_bf16_bwd(dpooled.contiguous().data_ptr(), n, t * h * w, channels, dx.data_ptr(),
+                                                 ops._stream()), "zsv_meanpool_bf16_bwd")
+    return dx
+
+
+# ---- one Conv3d -> BatchNorm3d (-> + residual) (-> ReLU) unit -----------------------------------------------------------
+class _Unit:
+    def __init__(self, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool):
+        if bn is None:
+            raise RuntimeError("amp: every trunk convolution is followed by a BatchNorm3d in the reference's VideoResNet")
+        if conv.bias is not None or tuple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+            raise RuntimeError("amp: bias / dilation / groups are not used by the reference's trunks and not supported")
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
+        self.kernel = tuple(conv.weight.shape[2:])
+        self.stride, self.padding = tuple(conv.stride), tuple(conv.padding)
+        self.folded = self.cin <= 4            # the clip itself: border materialised, kw folded into K (conv_bf16.hip)
+
+    def desc(self, n, t, h, w, folded_wo=None) -> ConvDesc:
+        """``h, w``: stored extents of the input (with the materialised border for the clip convolution)."""
+        kt, kh, kw = self.kernel
+        pt, ph, pw = self.padding
+        if self.folded:
+            ph = pw = 0
+        st, sh, sw = self.stride
+        to = (t + 2 * pt - kt) // st + 1
+        ho = (h + 2 * ph - kh) // sh + 1
+        wo = (w + 2 * pw - kw) // sw + 1 if folded_wo is None else folded_wo
+        return ConvDesc(n, self.cin, t, h, w, self.cout, to, ho, wo, kt, kh, kw, st, sh, sw, pt, ph, pw)
+
+
+class _Record:
+    __slots__ = ("unit", "x", "z", "y", "mean", "invstd", "desc", "has_res", "clips")
+
+
+def _units(mods) -> List[_Unit]:
+    return [_Unit(o._conv, o._bn, o.relu) for o in _conv_bn_relu_chain(list(mods), keep_modules=True)]
+
+
+class Bf16TrainPath:
+    """The trunk of a ``resnet.VideoResNet`` (BasicBlock models) as a list of Conv-BN units, with its forward tape and the
+    backward walk.  Built once per trunk (``train_path_for``); holds no weights of its own (the fp32 parameters are packed to
+    bf16 every step, after the optimizer moved them)."""
+
+    def __init__(self, trunk: nn.Module):
+        from . import resnet
+        if not isinstance(trunk, resnet.VideoResNet):
+            raise RuntimeError("amp: a resnet.VideoResNet trunk is expected")
+        self.trunk = trunk
+        self.stem = _units(trunk.stem)
+        if not self.stem[0].folded:
+            raise RuntimeError("amp: the stem's first convolution must take the clip (<= 4 channels)")
+        self.blocks = []
+        for layer in (trunk.layer1, trunk.layer2, trunk.layer3, trunk.layer4):
+            for block in layer:
+                if not isinstance(block, resnet.BasicBlock):
+                    raise RuntimeError("amp: only BasicBlock trunks (the reference's *_18 models) are supported")
+                main = _units(list(block.conv1)) + _units(list(block.conv2))
+                main[-1].relu = True                 # out += residual; relu (resnet.py:110-111)
+                down = _units(list(block.downsample)) if block.downsample is not None else None
+                if down is not None and len(down) != 1:
+                    raise RuntimeError("amp: the shortcut is one 1x1x1 convolution + BatchNorm (resnet.py:266-273)")
+                self.blocks.append((main, down[0] if down else None))
+        self.features = self.blocks[-1][0][-1].cout
+        units = list(self.stem)
+        for main, down in self.blocks:
+            units += ([down] if down is not None else []) + main
+        self.units = units
+        # parameter order of the autograd Function: weight, gamma, beta per unit
+        self.params = []
+        for u in units:
+            self.params += [u.conv.weight, u.bn.weight, u.bn.bias]
+
+    # -- forward -------------------------------------------------------------------------------------------------------
+    def _unit_fwd(self, u: _Unit, x: torch.Tensor, tape, residual=None, clips=None, wo=None):
+        n, t, h, w, _ = x.shape
+        d = u.desc(n, t, h, w, wo)
+        blob = pack_conv(d, u.conv.weight.detach(), None, None)
+        z = conv_bf16(d, x, blob, None, False)
+        y, mean, invstd = bn_cl_fwd_train(z, u.bn, residual, u.relu)
+        if tape is not None:
+            r = _Record()
+            r.unit, r.x, r.z, r.y, r.mean, r.invstd, r.desc, r.has_res, r.clips = u, x, z, y, mean, invstd, d, residual is not None, clips
+            tape.append(r)
+        return y
+
+    def forward(self, clips: torch.Tensor, tape):
+        first = self.stem[0]
+        n, _, t, h, w = clips.shape
+        kt, kh, kw = first.kernel
+        ph, pw = first.padding[1], first.padding[2]
+        wo = (w + 2 * pw - kw) // first.stride[2] + 1
+        hp, wp = h + 2 * ph, max(w + 2 * pw, (wo - 1) * first.stride[2] + 8)
+        x = clip_to_bf16(clips, ph, pw, hp, wp)
+        x = self._unit_fwd(first, x, tape, clips=clips, wo=wo)
+        for u in self.stem[1:]:
+            x = self._unit_fwd(u, x, tape)
+        for main, down in self.blocks:
+            residual = x if down is None else self._unit_fwd(down, x, tape)
+            y = x
+            for u in main[:-1]:
+                y = self._unit_fwd(u, y, tape)
+            x = self._unit_fwd(main[-1], y, tape, residual=residual)
+        return x
+
+    # -- backward pieces -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _dgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:
+        """Input gradient of the unit's convolution: the stride-1 convolution of the (zero-interleaved) output gradient with
+        the transposed, tap-flipped weights -- on the forward kernel."""
+        u, d = r.unit, r.desc
+        kt, kh, kw = u.kernel
+        st, sh, sw = u.stride
+        pt, ph, pw = u.padding
+        tu, hu, wu = d.Ti + 2 * pt - kt + 1, d.Hi + 2 * ph - kh + 1, d.Wi + 2 * pw - kw + 1
+        if (st, sh, sw) != (1, 1, 1):
+            up = torch.zeros((d.N, tu, hu, wu, dz.shape[-1]), dtype=torch.bfloat16, device=dz.device)
+            up[:, 0:(d.To - 1) * st + 1:st, 0:(d.Ho - 1) * sh + 1:sh, 0:(d.Wo - 1) * sw + 1:sw] = dz
+        else:
+            up = dz
+        wt = u.conv.weight.detach().transpose(0, 1).flip(2, 3, 4).contiguous()
+        d2 = ConvDesc(d.N, u.cout, tu, hu, wu, u.cin, d.Ti, d.Hi, d.Wi, kt, kh, kw, 1, 1, 1, kt - 1 - pt, kh - 1 - ph, kw - 1 - pw)
+        blob = pack_conv(d2, wt, None, None)
+        return conv_bf16(d2, up, blob, None, False)
+
+    @staticmethod
+    def _wgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:
+        """fp32 accumulation of the bf16-rounded operands (first slice: through the fp32 NCDHW weight-gradient kernels)."""
+        u, d = r.unit, r.desc
+        lib = _lib.load()
+        if u.folded:
+            x32 = r.clips.contiguous()                               # the fp32 clip itself (the stem has no bf16 copy in NCDHW)
+            kt, kh, kw = u.kernel
+            n, c, t, h, w = x32.shape
+            df = ops.conv_desc(x32.shape, u.conv.weight.shape, u.stride, u.padding)
+        else:
+            x32 = cl_to_ncdhw_f32(r.x, u.cin)
+            df = ops.conv_desc(x32.shape, u.conv.weight.shape, u.stride, u.padding)
+        dz32 = cl_to_ncdhw_f32(dz, u.cout)
+        if (df.To, df.Ho, df.Wo) != tuple(dz32.shape[2:]):
+            raise RuntimeError(f"amp: output gradient {tuple(dz32.shape)} does not match the convolution geometry")
+        nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(df))
+        weight = u.conv.weight
+
+        def launch(stream):
+            out = torch.empty_like(weight)
+            ws = ops._workspace(nbytes, dz.device)
+            _lib.check(lib.zsv_conv3d_wgrad(byref(df), x32.data_ptr(), dz32.data_ptr(), out.data_ptr(), ops._ptr(ws), nbytes,
+                                            stream), "zsv_conv3d_wgrad")
+            return out
+
+        return ops._on_wgrad_stream(launch, (x32, dz32), weight)
+
+    def backward(self, tape: List[_Record], dfeat: torch.Tensor, need_weight_grads=True):
+        """``dfeat``: gradient of the last block's output (channels-last bf16).  Returns {parameter id: gradient}."""
+        grads = {}
+        idx = len(tape) - 1
+
+        def unit_bwd(dy, want_g=False, need_dx=True):
+            nonlocal idx
+            r = tape[idx]
+            idx -= 1
+            u = r.unit
+            dz, g, dgamma, dbeta = bn_cl_bwd(dy, r.y, r.z, u.bn, r.mean, r.invstd, u.relu, want_g)
+            grads[id(u.bn.weight)] = dgamma
+            grads[id(u.bn.bias)] = dbeta
+            if need_weight_grads and u.conv.weight.requires_grad:
+                grads[id(u.conv.weight)] = self._wgrad(r, dz)
+            dx = self._dgrad(r, dz) if need_dx else None
+            return dx, g, r
+
+        dx = dfeat
+        for main, down in reversed(self.blocks):
+            # tail unit: BatchNorm + residual + ReLU -- the masked gradient is also the residual branch's gradient
+            dy, g, r_tail = unit_bwd(dx, want_g=True)
+            for _ in main[:-1]:
+                dy, _, _ = unit_bwd(dy)
+            if down is not None:
+                dxd, _, _ = unit_bwd(g)
+                dx = dy + dxd
+            else:
+                dx = dy + g
+        for i in range(len(self.stem) - 1, -1, -1):
+            dx, _, _ = unit_bwd(dx, need_dx=(i > 0))
+        assert idx == -1
+        return grads
+
+
+def train_path_for(trunk: nn.Module) -> Bf16TrainPath:
+    path = trunk.__dict__.get("_zsv_bf16_train_path")
+    if path is None:
+        path = trunk.__dict__["_zsv_bf16_train_path"] = Bf16TrainPath(trunk)
+    return path
+
+
+class _TrunkBf16(Function):
+    """pooled (N, 512) fp32 = mean over voxels of the trunk's last feature map, computed in bf16; gradients for the clip are
+    not produced (the clip is data), gradients for every trunk parameter are fp32."""
+
+    @staticmethod
+    def forward(ctx, clips, path, *params):
+        ops._require(clips)
+        tape = [] if any(p.requires_grad for p in params) else None
+        with torch.cuda.device(clips.device):
+            feat = path.forward(clips.contiguous(), tape)
+            pooled = meanpool_bf16(feat, path.features)
+        ctx.path, ctx.tape, ctx.feat_like = path, tape, feat
+        ctx.n_params = len(params)
+        ctx.set_materialize_grads(False)
+        return pooled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpooled):
+        path, tape = ctx.path, ctx.tape
+        if dpooled is None or tape is None:
+            return (None, None) + (None,) * ctx.n_params
+        with torch.cuda.device(dpooled.device):
+            dfeat = meanpool_bf16_bwd(dpooled.float(), ctx.feat_like, path.features)
+            grads = path.backward(tape, dfeat)
+        ctx.tape = None
+        out = []
+        for i, p in enumerate(path.params):
+            g = grads.get(id(p)) if ctx.needs_input_grad[2 + i] else None
+            out.append(g)
+        return (None, None) + tuple(out)
+
+
+def trunk_features(trunk: nn.Module, clips: torch.Tensor) -> torch.Tensor:
+    """``VideoResNet.forward``'s pooled output (resnet.py:251-254) for (N, 3, T, H, W) fp32 clips, trunk in bf16, train mode."""
+    if not clips.is_cuda:
+        raise RuntimeError("amp: MI355X HIP tensors only (there is no CPU fallback)")
+    path = train_path_for(trunk)
+    _lib.note_raw_write(parameters=False)               # BatchNorm running statistics are written through raw pointers
+    return _TrunkBf16.apply(clips, path, *path.params)

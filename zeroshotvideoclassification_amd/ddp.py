@@ -31,12 +31,37 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
 from . import _lib
 
 DEFAULT_BUCKET_BYTES = 25 * 1024 * 1024
+
+
+@torch.no_grad()
+def broadcast_tensors(tensors, src: int = 0, group=None) -> int:
+    """Every rank takes rank ``src``'s values of ``tensors`` (parameters, buffers): ONE collective per dtype over a flat
+    staging buffer instead of one per tensor (R(2+1)D-18: 304 tensors -> 2 broadcasts).  Returns the number of collectives.
+    The source rank's tensors are not written."""
+    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    rank = dist.get_rank()
+    calls = 0
+    for dtype, group_tensors in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in group_tensors])
+        dist.broadcast(flat, src=src, group=group)
+        calls += 1
+        if rank != src:
+            off = 0
+            for t in group_tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+    return calls
 
 
 class _Bucket:
@@ -75,7 +100,16 @@ class GradientSync:
         self._in_step = False
         self._cuda = any(p.is_cuda for p in self.params)
         self._side = torch.cuda.Stream() if self._cuda else None
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        # (ops._dw_read_early: a post-accumulate hook normally reads `.grad` on the backward stream, so the weight-gradient side
+        # stream is joined before it runs; THIS hook joins that stream itself in `_launch`, and says so to keep the overlap)
+        owner = weakref.ref(self)
+
+        def on_grad(p):
+            me = owner()
+            if me is not None:
+                me._on_grad(p)
+        on_grad._zsv_joins_wgrad = True
+        self._hooks = [p.register_post_accumulate_grad_hook(on_grad) for p in self.params]
         self.bytes_reduced_last_step = 0
         if broadcast_initial_state and self.world > 1:
             self.broadcast_state()
@@ -83,10 +117,10 @@ class GradientSync:
     # -- setup ---------------------------------------------------------------------------
     @torch.no_grad()
     def broadcast_state(self, src: int = 0) -> None:
-        """Every replica starts from rank ``src``'s parameters and buffers."""
-        for t in list(self.model.parameters()) + list(self.model.buffers()):
-            dist.broadcast(t.data, src=src, group=self.group)
-        _lib.note_raw_write()                      # `.data` writes do not bump the version counters
+        """Every replica starts from rank ``src``'s parameters and buffers (``src``: a global rank)."""
+        broadcast_tensors(list(self.model.parameters()) + list(self.model.buffers()), src, self.group)
+        if dist.get_rank() != src:
+            _lib.note_raw_write()                  # `.data` writes do not bump the version counters
 
     def _build_buckets(self, order: List[int]) -> None:
         buckets, cur, cur_bytes = [], [], 0

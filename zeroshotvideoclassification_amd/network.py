@@ -91,6 +91,16 @@ class Model(nn.Module):
 
     def forward(self, x):
         bs, nc, ch, t, h, w = x.shape
+        from . import amp
+        if amp.is_autocast_enabled() and x.is_cuda:            # main.py:172 `with autocast():` -> the bf16 paths
+            from . import resnet
+            if isinstance(self.model, resnet.VideoResNet):
+                if self.training:
+                    pooled = amp.trunk_features(self.model, x.reshape(bs * nc, ch, t, h, w))
+                    return F.normalize(self.output2emb_proj(pooled)), None
+                if not torch.is_grad_enabled():
+                    from .inference import engine_for
+                    return engine_for(self, torch.bfloat16)(x)
         _, feats = self.model(x.reshape(bs * nc, ch, t, h, w))
         pooled = ops.mean_pool(feats)                          # torch.mean(feats, dim=(2,3,4)), network.py:595
         emb = F.normalize(self.output2emb_proj(pooled))        # network.py:596

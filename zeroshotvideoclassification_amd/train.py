@@ -57,19 +57,63 @@ def embed(model: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
     return out[0] if isinstance(out, tuple) else out
 
 
+class StepPacer:
+    """Bounds how far the host may run ahead of the device: ``wait()`` at the head of a step blocks until the step
+    ``depth`` steps back has finished on the device.
+
+    The reference's loop reads ``loss.item()`` every iteration (main.py:203), i.e. it never runs ahead at all.  This path
+    has no host sync in a step, and a host that queues step k+1 while step k still runs cannot reuse the activation blocks
+    the weight-gradient stream still holds (``Tensor.record_stream``): every step of lead costs one more set of saved
+    activations (8-11 GB at 22 clips) taken from the driver by hipMalloc inside the loop.  With few launches per step
+    (C3D: ~130) the host would be many steps ahead within milliseconds.  ``depth = 2`` keeps one whole step queued behind
+    the running one (the device never idles) and the pool at three sets, reached after three steps."""
+
+    def __init__(self, depth: int = 2):
+        from collections import deque
+        self.depth = max(1, int(depth))
+        self.marks = deque()
+        self.waits = 0                 # steps whose head really had to wait (diagnostics)
+
+    def wait(self) -> None:
+        while len(self.marks) >= self.depth:
+            ev = self.marks.popleft()
+            if not ev.query():
+                self.waits += 1
+                ev.synchronize()
+
+    def mark(self) -> None:
+        ev = torch.cuda.Event()
+        ev.record()
+        self.marks.append(ev)
+
+    def drain(self) -> None:
+        self.marks.clear()
+
+
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion, x: torch.Tensor,
-               z: torch.Tensor, grad_sync=None, scaler=None) -> Tuple[torch.Tensor, torch.Tensor]:
+               z: torch.Tensor, grad_sync=None, scaler=None, pacer: Optional[StepPacer] = None,
+               autocast: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """One iteration of main.py:170-203.  ``grad_sync`` (a ``ddp.GradientSync``) all-reduces the
     gradients across ranks, overlapped with backward, before the optimizer step.  ``scaler`` (an
     ``optim.LossScaler`` or a ``torch.cuda.amp.GradScaler``) reproduces main.py:195-203:
     ``scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`` -- a non-finite gradient skips
-    the update and halves the scale.  (The reference's fp16 autocast forward, main.py:172, is not reproduced:
-    the training forward stays fp32, where the scaler only ever sees finite gradients unless the loss blows up.)"""
+    the update and halves the scale.  ``autocast=True`` runs forward and loss inside ``amp.autocast()`` -- main.py:172's
+    ``with autocast():`` -- i.e. the VideoResNet trunks in bf16 (``amp``: bf16 activations and products, fp32 accumulation,
+    statistics, parameters, gradients and loss); the default is the fp32 step of BASELINE configs 1-3, which is what the
+    reference's CPU path runs (autocast is a no-op there).  ``pacer`` (a ``StepPacer``) bounds the host's lead over the device."""
+    if pacer is not None:
+        pacer.wait()
     optimizer.zero_grad(set_to_none=True)
     if grad_sync is not None:
         grad_sync.begin_step()
-    y = embed(model, x)
-    loss = criterion(y, z)
+    if autocast:
+        from . import amp
+        with amp.autocast():
+            y = embed(model, x)
+            loss = criterion(y, z)
+    else:
+        y = embed(model, x)
+        loss = criterion(y, z)
     (scaler.scale(loss) if scaler is not None else loss).backward()
     ops.join_wgrad_streams()          # (the autograd end-of-pass callback has done this already; a no-op wait then)
     if grad_sync is not None:
@@ -79,6 +123,8 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criteri
         scaler.update()
     else:
         optimizer.step()
+    if pacer is not None:
+        pacer.mark()
     return y.detach(), loss.detach()
 
 
@@ -167,8 +213,9 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
     under one-process ``nn.DataParallel`` (main.py:126,250), which scatters each batch and runs every replica
     with DEVICE 0's parameters and BatchNorm running statistics.  Data-parallel training keeps those statistics
     per replica (``ddp.GradientSync``), so before a sharded evaluation every rank takes rank 0's parameters and
-    buffers (``sync_state``; one broadcast per tensor): all samples are scored by ONE model -- the one rank 0
-    would checkpoint (main.py:361-365).  ``sync_state=False`` skips the broadcast when the caller knows the
+    buffers (``sync_state``; one flat broadcast per dtype): all samples are scored by ONE model -- the one rank 0
+    would checkpoint (main.py:361-365).  NOTE: this overwrites the other ranks' BatchNorm running statistics, mid-training
+    too -- what ``nn.DataParallel`` does implicitly every forward.  ``sync_state=False`` skips the broadcast when the caller knows the
     replicas are identical (e.g. right after ``load_weights`` on every rank)."""
     import torch.distributed as dist
     if sharded is None:
@@ -178,9 +225,10 @@ def evaluate(model: torch.nn.Module, batches: Iterable[Sequence[torch.Tensor]], 
     model.eval()
     if sharded and sync_state:
         src = 0 if group is None else dist.get_global_rank(group, 0)
-        for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
-        _lib.note_raw_write()                              # `.data` writes: cached folded-BatchNorm engines must rebuild
+        from .ddp import broadcast_tensors
+        broadcast_tensors(list(model.parameters()) + list(model.buffers()), src, group)      # one collective per dtype
+        if dist.get_rank() != src:                         # (the source's values did not change: its panels / engines stay)
+            _lib.note_raw_write()                          # `.data` writes: cached folded-BatchNorm engines must rebuild
     device = device or next(model.parameters()).device
     forward = model
     if dtype in (torch.bfloat16, torch.float32):
