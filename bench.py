@@ -22,8 +22,9 @@ PCIe-inclusive rate, never the headline).  Rank 0 prints ONE JSON line.  Extra o
 * ``cpu_baseline``: the CPU oracle (oracle/restatement.py, pinned to the reference) timed on
   this host's cores on a bounded sample (N = 2 clips), rank 0 at N = 1 only;
 * ``host_enqueue_ms``: host time to queue one step's launches (no device sync inside);
-* ``extra``: after everything else, N = 1 only: BASELINE.json configs[3] (C3D training step)
-  and configs[4]'s per-GPU work (32-frame bf16 ``evaluate()`` protocol), 5 steps / 6 batches each.
+* ``extra``: after everything else, N = 1 only: BASELINE.json configs[3] (C3D training step),
+  configs[4]'s per-GPU work (32-frame bf16 ``evaluate()`` protocol) and the mixed-precision (bf16)
+  training step of SURVEY row a12 (``extra.train_bf16``: never the headline).
 """
 from __future__ import annotations
 
@@ -474,6 +475,65 @@ def extra_c3d(dev, steps=10, warmup=3):
     return out
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0       # dense bf16 matrix peak (MI355X_MICROARCH.md); the sparsity figure is never used
+
+
+def extra_train_bf16(dev, steps=10, warmup=6):
+    """SURVEY row a12, never the headline: the reference's mixed-precision step (main.py:172 `with autocast():` +
+    main.py:137,195-203 GradScaler) on the bf16 training path (amp.py): R(2+1)D-18, 22 clips, bf16 activations and products,
+    fp32 accumulation / statistics / parameters / loss, `optim.LossScaler` driving `optim.FusedAdam`."""
+    from types import SimpleNamespace
+    from zeroshotvideoclassification_amd import network, ops, optim, synthetic, train
+    model = network.get_network(SimpleNamespace(network="r2plus1d_18", fixconvs=False, nopretrained=False))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
+    model.to(dev).train()
+    criterion = torch.nn.MSELoss().to(dev)
+    optimizer = optim.FusedAdam(model.parameters(), lr=1e-3)
+    scaler = optim.LossScaler(init_scale=2.0 ** 16)
+    x = synthetic.synthetic_clips(CLIPS_PER_GPU, FRAMES, SIZE).to(dev)
+    _, z = synthetic.synthetic_targets(CLIPS_PER_GPU)
+    z = z.to(dev)
+    pacer = train.StepPacer(pacer_depth()) if pacer_depth() > 0 else None
+
+    def step():
+        return train.train_step(model, optimizer, criterion, x, z, scaler=scaler, pacer=pacer, autocast=True)
+
+    step()
+    torch.cuda.synchronize()
+    run_queued(step, max(warmup - 1, 1))
+    geometry = dict(S1_GEOMETRY, N=CLIPS_PER_GPU)
+    timer = ops.KernelTimer("conv_bf16_fwd", geometry)
+    ops.KERNEL_TIMER = timer
+    a = allocator_snapshot(dev)
+    wall, host, dev_ms, behind, (_, loss) = run_queued(step, steps)
+    b = allocator_snapshot(dev)
+    ops.KERNEL_TIMER = None
+    value = CLIPS_PER_GPU * steps / wall
+    out = {"workload": f"r2plus1d_18 MIXED-PRECISION training step (zero_grad + autocast(fwd + MSE) + scaled bwd + unscale / inf check + Adam), "
+                       f"{CLIPS_PER_GPU} clips 3x{FRAMES}x{SIZE}x{SIZE}: bf16 activations / products, fp32 accumulation, statistics, parameters, "
+                       "loss (main.py:172,137,195-203; SURVEY row a12; not a BASELINE.json config, never the headline)",
+           "value": round(value, 2), "unit": "clips/s", "steps": steps, "warmup": warmup, "dtype": "bf16 (fp32 accumulate)",
+           "ms_per_step": round(1e3 * wall / steps, 3), "median_step_ms_on_device": round(statistics.median(dev_ms), 3),
+           "host_queued_all_after_ms": round(1e3 * host[-1], 2), "host_lead_steps": behind,
+           "allocator_in_timed_region": allocator_delta(a, b), "final_loss": float(loss.item()),
+           "loss_scale": float(scaler.get_scale()) if hasattr(scaler, "get_scale") else None,
+           "step_roofline": {"bf16_flop_frac_algorithmic": round(value * 242.5e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                             "note": "242.5 GFLOP/clip (SURVEY 8d) against the 2.5 PFLOP/s dense bf16 matrix peak; the step is bound by HBM "
+                                     "(BatchNorm passes), L2->LDS operand traffic and launches, not by the matrix pipe"}}
+    if timer.pairs:
+        ms = timer.durations_ms()
+        mean_ms = sum(ms) / len(ms)
+        gm = S1_GEOMETRY
+        flops = 2.0 * CLIPS_PER_GPU * gm["Cout"] * gm["Cin"] * 9 * gm["Ti"] * gm["Hi"] * gm["Wi"]
+        tf = flops / (mean_ms * 1e-3) / 1e12
+        out["dominant_kernel"] = {"kernel": "zsv::conv_bf16_same_kernel<9, 4, 1, 4> = Conv3d(64,144,(1,3,3)) forward @16x56x56 on channels-last bf16 "
+                                            "(v_mfma_f32_16x16x32_bf16), 4 launches/step",
+                                  "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tf / BF16_MFMA_PEAK_TFLOPS, 4), "mean_launch_ms": round(mean_ms, 4),
+                                  "launches_timed": len(ms)}
+    return out
+
+
 def extra_eval_t32_bf16(dev, batches=6, repeats=5):
     """BASELINE.json configs[4] per GPU: the reference's ``evaluate()`` protocol (main.py:224-313) on 32-frame clips
     with the bf16 engine: eval forward + cosine nearest class + the 10 half-class splits, three class tables."""
@@ -731,7 +791,7 @@ def main():
             del model, optimizer, x
             torch.cuda.empty_cache()
             extra = {}
-            for name, fn in (("c3d", extra_c3d), ("eval_t32_bf16", extra_eval_t32_bf16)):
+            for name, fn in (("c3d", extra_c3d), ("eval_t32_bf16", extra_eval_t32_bf16), ("train_bf16", extra_train_bf16)):
                 try:
                     log(f"extra.{name} ...")
                     extra[name] = fn(dev)

@@ -250,6 +250,11 @@ int32_t zsv_bf16_channel_pitch(int32_t channels);
 size_t zsv_conv3d_bf16_blob_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* scale, const float* shift,
                          void* blob, void* stream);
+/* The blob of the INPUT-GRADIENT problem of a convolution (bf16 training step, amp.py): `d` describes that problem -- a
+ * stride-1 convolution of the (zero-interleaved) output gradient, d->Cin = the forward's Cout, d->Cout = the forward's Cin,
+ * padding k-1-p -- and `w_fwd` is the FORWARD weight (forward Cout, forward Cin, kT, kH, kW) as the module holds it: channel
+ * roles are swapped and the taps flipped while packing (aten::convolution_backward's input gradient, resnet.py:40-52). */
+int zsv_conv3d_bf16_pack_dgrad(const zsv_conv_desc* d, const float* w_fwd, void* blob, void* stream);
 int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual,
                         int fuse_relu, void* y, void* stream);
 /* (N, C<=4, T, H, W) fp32 clip -> [N][T][Hp][Wp][4] bf16, the frame placed at (padH, padW) inside a
@@ -276,6 +281,14 @@ int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t 
 int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
                   const float* save_invstd, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* Weight gradient of a stride-1 "same" convolution from channels-last bf16 operands (x [N][T][H][W][CinP], dz
+ * [N][T][H][W][CoutP]) with fp32 accumulation: dw (Cout, Cin, kT, kH, kW) fp32 -- aten::convolution_backward's weight
+ * gradient under autocast (resnet.py:40-52 1x3x3 / 3x1x1, resnet.py:23-30 3x3x3).  The workspace holds per-slice partial
+ * sums; zsv_conv3d_bf16_wgrad_workspace_bytes() == 0 means "not this kernel's geometry" (strided, 1x1x1, the clip
+ * convolution): the caller converts the operands (below) and uses zsv_conv3d_wgrad. */
+size_t zsv_conv3d_bf16_wgrad_workspace_bytes(const zsv_conv_desc* d);
+int zsv_conv3d_bf16_wgrad(const zsv_conv_desc* d, const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* layout converters between the two activation layouts: [N][S][Cp] bf16 <-> (N, C, S) fp32 (C > 4; pad channels read as /
  * written with zero): they hand a bf16 tensor to the fp32 NCDHW kernels (weight gradients of the mixed-precision step). */
 int zsv_cl_bf16_to_ncs_f32(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);

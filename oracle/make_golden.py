@@ -438,8 +438,21 @@ def run_autocast_bf16():
         samples.append(smp)
     out["grad_names"], out["grad_norm"], out["grad_sample"] = np.array(names), np.array(norms), np.stack(samples)
     sd = ref.state_dict()
+    grads16 = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}
     out["running_mean_after1"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_mean")])
     out["running_var_after1"] = np.concatenate([sd[k].numpy() for k in sd if k.endswith("running_var")])
+    # how far the reference's OWN bf16 gradients are from its fp32 gradients on this problem (random-init weights, a loss
+    # gradient that is tiny next to bf16's rounding of the activations): the noise floor the HIP path is held to
+    ref.load_state_dict(weights)
+    ref.train()
+    ref.zero_grad()
+    F.mse_loss(R.embed(ref, x), z).backward()
+    cosines = []
+    for k in names:
+        a, b = grads16[k].double().flatten(), dict(ref.named_parameters())[k].grad.double().flatten()
+        cosines.append(float(a @ b / (a.norm() * b.norm() + 1e-300)))
+    out["grad_cos_vs_f32"] = np.array(cosines)
+    out["grad_norm_f32"] = np.array([dict(ref.named_parameters())[k].grad.double().norm().item() for k in names])
     for tag, autocast in (("bf16", True), ("f32", False)):
         ref.load_state_dict(weights)
         ref.train()

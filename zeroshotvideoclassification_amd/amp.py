@@ -17,8 +17,10 @@ scaling is needed for its exponent range, the scaler is supported all the same):
   packed to bf16 once per step; train-mode BatchNorm + ReLU + residual: ``zsv_bn_cl_fwd_train`` (csrc/train_bf16.hip);
 * input gradient: the same convolution kernel on the transposed, tap-flipped weights (a strided convolution's gradient is
   the stride-1 convolution of the zero-interleaved output gradient); BatchNorm / ReLU backward: ``zsv_bn_cl_bwd``;
-* weight gradient: fp32 accumulation of bf16-rounded operands.  This first slice converts the two operands to the fp32
-  NCDHW layout (``zsv_cl_bf16_to_ncs_f32``) and runs the fp32 weight-gradient kernels of the main path;
+* weight gradient: fp32 accumulation of the bf16 operands.  The stride-1 "same" convolutions (1x3x3, 3x1x1, 3x3x3) run
+  ``zsv_conv3d_bf16_wgrad`` (csrc/wgrad_bf16.hip: the contraction runs over voxels, the operands are staged as they lie in
+  memory and read back through gfx950's transposed LDS read); strided convolutions, the 1x1x1 shortcuts and the clip
+  convolution convert the two operands to fp32 NCDHW (``zsv_cl_bf16_to_ncs_f32``) and use the fp32 kernels of the main path;
 * the pooled 512-d feature, the MLP head, normalisation and the loss stay fp32 (``ops``), as under autocast's fp32 list.
 
 The whole trunk is ONE ``torch.autograd.Function`` (its forward keeps its own tape): autograd sees
@@ -92,7 +94,11 @@ def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torc
                                        1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
                                        ops._stream()), "zsv_bn_cl_fwd_train")
     if track:
-        bn.num_batches_tracked.add_(1)
+        pending = getattr(_state, "nbt_pending", None)
+        if pending is not None:
+            pending.append(bn.num_batches_tracked)       # one _foreach_add_ at the end of the trunk instead of 37 one-element launches
+        else:
+            bn.num_batches_tracked.add_(1)
     return y, mean, invstd
 
 
@@ -215,7 +221,11 @@ class Bf16TrainPath:
         n, t, h, w, _ = x.shape
         d = u.desc(n, t, h, w, wo)
         blob = pack_conv(d, u.conv.weight.detach(), None, None)
+        timer = ops.KERNEL_TIMER
+        mark = timer.start() if timer is not None and timer.wants("conv_bf16_fwd", d) else None
         z = conv_bf16(d, x, blob, None, False)
+        if mark is not None:
+            timer.stop(mark)
         y, mean, invstd = bn_cl_fwd_train(z, u.bn, residual, u.relu)
         if tape is not None:
             r = _Record()
@@ -257,29 +267,47 @@ class Bf16TrainPath:
             up[:, 0:(d.To - 1) * st + 1:st, 0:(d.Ho - 1) * sh + 1:sh, 0:(d.Wo - 1) * sw + 1:sw] = dz
         else:
             up = dz
-        wt = u.conv.weight.detach().transpose(0, 1).flip(2, 3, 4).contiguous()
         d2 = ConvDesc(d.N, u.cout, tu, hu, wu, u.cin, d.Ti, d.Hi, d.Wi, kt, kh, kw, 1, 1, 1, kt - 1 - pt, kh - 1 - ph, kw - 1 - pw)
-        blob = pack_conv(d2, wt, None, None)
+        lib = _lib.load()
+        nbytes = lib.zsv_conv3d_bf16_blob_bytes(byref(d2))
+        if nbytes == 0:
+            raise RuntimeError("zsv_conv3d_bf16_blob_bytes: unsupported input-gradient geometry")
+        blob = torch.empty(int(nbytes), dtype=torch.uint8, device=dz.device)
+        # (channel roles swapped and taps flipped while packing: no transposed copy of the weight)
+        _lib.check(lib.zsv_conv3d_bf16_pack_dgrad(byref(d2), u.conv.weight.detach().contiguous().data_ptr(), blob.data_ptr(),
+                                                  ops._stream()), "zsv_conv3d_bf16_pack_dgrad")
         return conv_bf16(d2, up, blob, None, False)
 
     @staticmethod
     def _wgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:
-        """fp32 accumulation of the bf16-rounded operands (first slice: through the fp32 NCDHW weight-gradient kernels)."""
+        """fp32 accumulation of the bf16-rounded operands.  Stride-1 "same" convolutions (1x3x3, 3x1x1, 3x3x3: 90 % of the
+        weight-gradient FLOPs) run ``zsv_conv3d_bf16_wgrad`` on the channels-last bf16 tensors as they are; the strided
+        convolutions, the 1x1x1 shortcuts and the clip convolution convert the two operands to fp32 NCDHW
+        (``zsv_cl_bf16_to_ncs_f32``) and use the fp32 weight-gradient kernels of the main path."""
         u, d = r.unit, r.desc
         lib = _lib.load()
+        weight = u.conv.weight
+        native = 0 if u.folded else int(lib.zsv_conv3d_bf16_wgrad_workspace_bytes(byref(d)))
+        if native:
+            x_cl = r.x
+
+            def launch_native(stream):
+                out = torch.empty_like(weight)
+                ws = ops._workspace(native, dz.device)
+                _lib.check(lib.zsv_conv3d_bf16_wgrad(byref(d), x_cl.data_ptr(), dz.data_ptr(), out.data_ptr(), ops._ptr(ws), native,
+                                                     stream), "zsv_conv3d_bf16_wgrad")
+                return out
+
+            return ops._on_wgrad_stream(launch_native, (x_cl, dz), weight)
         if u.folded:
             x32 = r.clips.contiguous()                               # the fp32 clip itself (the stem has no bf16 copy in NCDHW)
-            kt, kh, kw = u.kernel
-            n, c, t, h, w = x32.shape
-            df = ops.conv_desc(x32.shape, u.conv.weight.shape, u.stride, u.padding)
         else:
             x32 = cl_to_ncdhw_f32(r.x, u.cin)
-            df = ops.conv_desc(x32.shape, u.conv.weight.shape, u.stride, u.padding)
+        df = ops.conv_desc(x32.shape, u.conv.weight.shape, u.stride, u.padding)
         dz32 = cl_to_ncdhw_f32(dz, u.cout)
         if (df.To, df.Ho, df.Wo) != tuple(dz32.shape[2:]):
             raise RuntimeError(f"amp: output gradient {tuple(dz32.shape)} does not match the convolution geometry")
         nbytes = lib.zsv_conv3d_wgrad_workspace_bytes(byref(df))
-        weight = u.conv.weight
 
         def launch(stream):
             out = torch.empty_like(weight)
@@ -341,7 +369,13 @@ class _TrunkBf16(Function):
         ops._require(clips)
         tape = [] if any(p.requires_grad for p in params) else None
         with torch.cuda.device(clips.device):
-            feat = path.forward(clips.contiguous(), tape)
+            _state.nbt_pending = []
+            try:
+                feat = path.forward(clips.contiguous(), tape)
+            finally:
+                pending, _state.nbt_pending = _state.nbt_pending, None
+            if pending:
+                torch._foreach_add_(pending, 1)
             pooled = meanpool_bf16(feat, path.features)
         ctx.path, ctx.tape, ctx.feat_like = path, tape, feat
         ctx.n_params = len(params)

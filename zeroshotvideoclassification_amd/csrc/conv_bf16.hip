@@ -643,7 +643,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_tsame_kernel(Bf16Params prm,
 // Wp[q][Mp][32] <- w[Cout][Cin][kT][kH][kW] * scale[cout]; then Mp fp32 shifts.
 __global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                  const float* __restrict__ shift, __bf16* __restrict__ wp, float* __restrict__ shift_out,
-                                 int M, int Mp, int bm, int Cin, int taps, int nchunk, int kW, int folded, long total) {
+                                 int M, int Mp, int bm, int Cin, int taps, int nchunk, int kW, int folded, long total,
+                                 int transposed = 0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < Mp) shift_out[idx] = (idx < M && shift != nullptr) ? shift[idx] : 0.f;     // channel order
     if (idx >= total) return;
@@ -660,7 +661,9 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, const float* __res
             if (kwi < kW && c < Cin) v = w[(((long)row * Cin + c) * taps + q) * kW + kwi] * s;
         } else {
             const int tap = q / nchunk, ci = (q - tap * nchunk) * 32 + k;
-            if (ci < Cin) v = w[((long)row * Cin + ci) * taps + tap] * s;
+            // transposed: `w` is the FORWARD weight (Cin, M, taps) of the convolution whose input gradient this problem is:
+            // channel roles swapped, taps reversed (flip along kt, kh and kw = the linear tap index read backwards)
+            if (ci < Cin) v = (transposed ? w[((long)ci * M + row) * taps + (taps - 1 - tap)] : w[((long)row * Cin + ci) * taps + tap]) * s;
         }
     }
     wp[idx] = (__bf16)v;
@@ -834,6 +837,23 @@ int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* sc
     return launch_status();
 }
 
+int zsv_conv3d_bf16_pack_dgrad(const zsv_conv_desc* d, const float* w_fwd, void* blob, void* stream) {
+    if (d == nullptr) return ZSV_E_NULL;
+    const int st = bf16_check(d);
+    if (st != ZSV_OK) return st;
+    if (w_fwd == nullptr || blob == nullptr) return ZSV_E_NULL;
+    if (bf16_folded(d)) return ZSV_E_UNSUPPORTED;
+    const int bm = bf16_bm(d->Cout), Mp = round_up(d->Cout, bm);
+    const int taps = d->kT * d->kH * d->kW;
+    const int nchunk = round_up(d->Cin, 32) / 32;
+    const long total = (long)taps * nchunk * Mp * 32;
+    __bf16* wp = (__bf16*)blob;
+    float* shift_out = (float*)((char*)blob + total * 2);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_fwd, nullptr,
+                       nullptr, wp, shift_out, d->Cout, Mp, bm, d->Cin, taps, nchunk, d->kW, 0, total, 1);
+    return launch_status();
+}
+
 int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual, int fuse_relu,
                         void* y, void* stream) {
     if (d == nullptr) return ZSV_E_NULL;
@@ -877,6 +897,10 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
         if (bm == 144) return bf16_same_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
         return bf16_same_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     }
+    // 64 produced channels with many voxels: the input gradient of layer1's spatial convolutions in the bf16 training step
+    // (144 -> 64 channels, K = 9 x 160; amp.py) -- the per-tap kernel gathers every input row nine times for 64 rows of MFMAs
+    if (bf16_same_applicable(d) && bm == 64 && p.P >= 256 * 512 && ZSV_KNOB(BF16_NO_SAME64) == nullptr)
+        return bf16_same_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 144) return bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (small) return bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);

@@ -11,6 +11,8 @@
     X(NO_BN_FUSION) \
     X(BF16_NO_SAME) \
     X(BF16_NO_TSAME) \
+    X(BF16_NO_SAME64) \
+    X(BF16_NO_WGRAD) \
     X(NO_DGRAD_S2) \
     X(NO_DGRAD_S2T) \
     X(DGRAD_S2_BN) \
