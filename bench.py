@@ -65,8 +65,8 @@ DOMINANT = {
 }
 BASELINE_CONFIG = {"r2plus1d_18": "BASELINE.json configs[1]; configs[2] when n_gpus > 1", "c3d": "BASELINE.json configs[3]"}
 # committed PMC passes of the dominant kernel, newest first (counters cannot be read inside this process)
-PMC_BUSY_FILES = ("r03_s1_mfma_busy.json", "r02_s1_mfma_busy.json")
-PMC_TRAFFIC_FILES = ("r03_s1_hbm_traffic.json", "r02_s1_hbm_traffic.json")
+PMC_BUSY_FILES = ("r04_s1_mfma_busy.json", "r03_s1_mfma_busy.json", "r02_s1_mfma_busy.json")
+PMC_TRAFFIC_FILES = ("r04_s1_hbm_traffic.json", "r03_s1_hbm_traffic.json", "r02_s1_hbm_traffic.json")
 
 
 def free_port() -> int:

@@ -19,6 +19,7 @@ ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--size", type=int, default=112)
 ap.add_argument("--network", default="r2plus1d_18")
 ap.add_argument("--fp32", action="store_true", help="time the fp32 step instead (same loop)")
+ap.add_argument("--optimizer", choices=["torch", "fused"], default="torch")
 args = ap.parse_args()
 dev = torch.device("cuda")
 model = network.get_network(SimpleNamespace(network=args.network, fixconvs=False, nopretrained=False))
@@ -27,7 +28,7 @@ model.to(dev).train()
 x = synthetic.synthetic_clips(args.batch, args.frames, args.size).to(dev)
 _, z = synthetic.synthetic_targets(args.batch)
 z = z.to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = optim.FusedAdam(model.parameters(), lr=1e-3) if args.optimizer == "fused" else torch.optim.Adam(model.parameters(), lr=1e-3)
 crit = torch.nn.MSELoss()
 pacer = train.StepPacer(2)
 

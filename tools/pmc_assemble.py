@@ -30,7 +30,7 @@ for k, what in WHAT.items():
         traffic[k] = {"what": what, "FETCH_SIZE_KiB": f["FETCH_SIZE"], "WRITE_SIZE_KiB": w["WRITE_SIZE"], "read_bytes": rd, "write_bytes": wr,
                       "hbm_bytes": rd + wr, "duration_us_fetch_pass": f["duration_us"], "duration_us_write_pass": w["duration_us"]}
 src = ("rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 tools/conv_bench.py --shapes S1,T1 --kinds fwd,dgrad,wgrad --iters 3 --pre --stats "
-       f"(round {int(rnd)}, tools/r03_pmc_s1.sh: one own pass per counter set, no other trace domains; mean of the last 3 dispatches; tools/pmc_summary.py, tools/pmc_assemble.py)")
+       f"(round {int(rnd)}, tools/rNN_pmc*.sh: one own pass per counter set, no other trace domains; mean of the last 3 dispatches; tools/pmc_summary.py, tools/pmc_assemble.py)")
 json.dump({"source": src,
            "how_to_read": "SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs = 32 cycles per v_mfma_f32_16x16x4_f32; the direct kernel would execute 2,861,236,224 on S1 (89.4 M MFMAs = 183.1 GFLOP), "
                           "F(2,3) 2/3 of that, F(4,3) exactly 1/2; GRBM_GUI_ACTIVE is summed over the 8 XCDs; matrix-pipe utilisation = MFMA_BUSY / (1024 * GUI_ACTIVE / 8); clock = GUI_ACTIVE / 8 / duration",

@@ -254,29 +254,70 @@ class Bf16TrainPath:
 
     # -- backward pieces -----------------------------------------------------------------------------------------------
     @staticmethod
-    def _dgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:
-        """Input gradient of the unit's convolution: the stride-1 convolution of the (zero-interleaved) output gradient with
-        the transposed, tap-flipped weights -- on the forward kernel."""
-        u, d = r.unit, r.desc
-        kt, kh, kw = u.kernel
-        st, sh, sw = u.stride
-        pt, ph, pw = u.padding
-        tu, hu, wu = d.Ti + 2 * pt - kt + 1, d.Hi + 2 * ph - kh + 1, d.Wi + 2 * pw - kw + 1
-        if (st, sh, sw) != (1, 1, 1):
-            up = torch.zeros((d.N, tu, hu, wu, dz.shape[-1]), dtype=torch.bfloat16, device=dz.device)
-            up[:, 0:(d.To - 1) * st + 1:st, 0:(d.Ho - 1) * sh + 1:sh, 0:(d.Wo - 1) * sw + 1:sw] = dz
-        else:
-            up = dz
-        d2 = ConvDesc(d.N, u.cout, tu, hu, wu, u.cin, d.Ti, d.Hi, d.Wi, kt, kh, kw, 1, 1, 1, kt - 1 - pt, kh - 1 - ph, kw - 1 - pw)
+    def _axis_classes(k: int, p: int, s: int, n_in: int, n_out: int):
+        """Residue classes of one axis of a convolution's input gradient.  Input position i = s*j + rho receives
+        sum_m w[r + s*m] * dy[j + c - m] with r = (rho + p) mod s, c = (rho + p - r) / s: a stride-1 correlation of dy with the
+        taps of that residue.  Per class: (rho, r, taps, symmetric padding for the forward kernel, first useful output, count).
+        A stride-1 axis is the single class (0, 0, k, k-1-p, 0, n_in)."""
+        out = []
+        for rho in range(s):
+            count = (n_in - rho + s - 1) // s
+            if count <= 0:
+                continue
+            r = (rho + p) % s
+            taps = (k - r + s - 1) // s if k > r else 0
+            if taps == 0:
+                out.append((rho, r, 0, 0, 0, count))
+                continue
+            c = (rho + p - r) // s
+            pad = max(0, taps - 1 - c, c + count - n_out)
+            out.append((rho, r, taps, pad, c - taps + 1 + pad, count))
+        return out
+
+    @staticmethod
+    def _dgrad_problem(u: _Unit, dz: torch.Tensor, weight: torch.Tensor, kernel, pads, out_dims):
+        """One stride-1 convolution of ``dz`` with the (channel-swapped, tap-flipped) ``weight`` on the forward kernel."""
+        n, to, ho, wo, _ = dz.shape
+        kt, kh, kw = kernel
+        d2 = ConvDesc(n, u.cout, to, ho, wo, u.cin, out_dims[0], out_dims[1], out_dims[2], kt, kh, kw, 1, 1, 1, pads[0], pads[1], pads[2])
         lib = _lib.load()
         nbytes = lib.zsv_conv3d_bf16_blob_bytes(byref(d2))
         if nbytes == 0:
             raise RuntimeError("zsv_conv3d_bf16_blob_bytes: unsupported input-gradient geometry")
         blob = torch.empty(int(nbytes), dtype=torch.uint8, device=dz.device)
         # (channel roles swapped and taps flipped while packing: no transposed copy of the weight)
-        _lib.check(lib.zsv_conv3d_bf16_pack_dgrad(byref(d2), u.conv.weight.detach().contiguous().data_ptr(), blob.data_ptr(),
-                                                  ops._stream()), "zsv_conv3d_bf16_pack_dgrad")
-        return conv_bf16(d2, up, blob, None, False)
+        _lib.check(lib.zsv_conv3d_bf16_pack_dgrad(byref(d2), weight.data_ptr(), blob.data_ptr(), ops._stream()),
+                   "zsv_conv3d_bf16_pack_dgrad")
+        return conv_bf16(d2, dz, blob, None, False)
+
+    @staticmethod
+    def _dgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:
+        """Input gradient of the unit's convolution on the FORWARD kernel: a stride-1 convolution of the output gradient with the
+        transposed, tap-flipped weights.  A strided convolution splits into one such problem per residue class of the input
+        positions (stride (1,2,2): four classes with 1 / 2 / 2 / 4 of the nine taps on the compact output grid -- exactly the
+        forward's multiply count, where a zero-interleaved output gradient would cost four times as much); the class results
+        are interleaved into the input gradient."""
+        u, d = r.unit, r.desc
+        w = u.conv.weight.detach()
+        axes = [Bf16TrainPath._axis_classes(k, p, s, n_in, n_out) for k, p, s, n_in, n_out in
+                zip(u.kernel, u.padding, u.stride, (d.Ti, d.Hi, d.Wi), (d.To, d.Ho, d.Wo))]
+        if all(len(a) == 1 for a in axes):                          # stride 1: the result is the gradient itself
+            (ct, ch, cw) = (a[0] for a in axes)
+            return Bf16TrainPath._dgrad_problem(u, dz, w.contiguous(), u.kernel, (ct[3], ch[3], cw[3]), (d.Ti, d.Hi, d.Wi))
+        empty_class = any(c[2] == 0 for a in axes for c in a)
+        alloc = torch.zeros if empty_class else torch.empty
+        dx = alloc((d.N, d.Ti, d.Hi, d.Wi, channel_pitch(u.cin)), dtype=torch.bfloat16, device=dz.device)
+        st, sh, sw = u.stride
+        for ct in axes[0]:
+            for ch in axes[1]:
+                for cw in axes[2]:
+                    if ct[2] == 0 or ch[2] == 0 or cw[2] == 0:
+                        continue                                    # no tap reaches these positions (1x1x1 stride 2: 7 of 8 classes)
+                    sub = w[:, :, ct[1]::st, ch[1]::sh, cw[1]::sw].contiguous()
+                    dims = tuple(n_out + 2 * c[3] - c[2] + 1 for c, n_out in zip((ct, ch, cw), (d.To, d.Ho, d.Wo)))
+                    part = Bf16TrainPath._dgrad_problem(u, dz, sub, (ct[2], ch[2], cw[2]), (ct[3], ch[3], cw[3]), dims)
+                    dx[:, ct[0]::st, ch[0]::sh, cw[0]::sw] = part[:, ct[4]:ct[4] + ct[5], ch[4]:ch[4] + ch[5], cw[4]:cw[4] + cw[5]]
+        return dx
 
     @staticmethod
     def _wgrad(r: _Record, dz: torch.Tensor) -> torch.Tensor:

@@ -187,21 +187,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, con
             qhi[j] = tr_read(sb + q_off[j][1]);
         }
         // w-border masks of this lane's 8 voxels (kw = 0 needs w >= 1, kw = 2 needs w <= W - 2); voxel j sits in half (j & 1) of
-        // dword (j >> 1) & 1 of the lo (j < 4) / hi fragment
+        // dword (j >> 1) of the fragment.  With W >= 8 at most one voxel of the eight has w == 0 and at most one w == W - 1.
         unsigned m0[4], m2[4];
         if (KW == 3) {
             const int vb = chunk * 32 + 8 * g;
             int w = (int)((unsigned)vb - mdiv((unsigned)vb, prm.mW) * prm.W);
+            if (prm.W >= 8) {
+                const int j0 = w == 0 ? 0 : prm.W - w;                 // first voxel with w == 0 (>= 8: none)
+                const int j2 = prm.W - 1 - w;                          //                  w == W - 1
+                const unsigned k0 = (j0 & 1) ? 0x0000ffffu : 0xffff0000u, k2 = (j2 & 1) ? 0x0000ffffu : 0xffff0000u;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) { m0[d] = 0xffffffffu; m2[d] = 0xffffffffu; }
+                for (int d = 0; d < 4; ++d) {
+                    m0[d] = (j0 >> 1) == d ? k0 : 0xffffffffu;
+                    m2[d] = (j2 >> 1) == d ? k2 : 0xffffffffu;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned keep = (j & 1) ? 0x0000ffffu : 0xffff0000u;
-                if (w == 0) m0[j >> 1] &= keep;
-                if (w == prm.W - 1) m2[j >> 1] &= keep;
-                w = (w + 1 == prm.W) ? 0 : w + 1;
+                for (int d = 0; d < 4; ++d) { m0[d] = 0xffffffffu; m2[d] = 0xffffffffu; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned keep = (j & 1) ? 0x0000ffffu : 0xffff0000u;
+                    if (w == 0) m0[j >> 1] &= keep;
+                    if (w == prm.W - 1) m2[j >> 1] &= keep;
+                    w = (w + 1 == prm.W) ? 0 : w + 1;
+                }
             }
         }
+        wbf16x8 qf[KW][QB];                                            // the Q fragments of the three kw taps: formed once per chunk
+        bool q_ready = false;
 #pragma unroll
         for (int i = 0; i < NIMG; ++i) {
             wu32x2 plo[KW], phi[KW];
@@ -213,22 +226,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, con
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int c = 0; c < KW; ++c) { tie(plo[c]); tie(phi[c]); }
-            if (i == 0) {
+            if (!q_ready) {
+                q_ready = true;
 #pragma unroll
-                for (int j = 0; j < QB; ++j) { tie(qlo[j]); tie(qhi[j]); }
+                for (int j = 0; j < QB; ++j) {
+                    tie(qlo[j]);
+                    tie(qhi[j]);
+                    const wu32x4 qv = {qlo[j][0], qlo[j][1], qhi[j][0], qhi[j][1]};
+                    if (KW == 3) {
+                        const wu32x4 q0 = {qv[0] & m0[0], qv[1] & m0[1], qv[2] & m0[2], qv[3] & m0[3]};
+                        const wu32x4 q2 = {qv[0] & m2[0], qv[1] & m2[1], qv[2] & m2[2], qv[3] & m2[3]};
+                        qf[0][j] = __builtin_bit_cast(wbf16x8, q0);
+                        qf[KW / 2][j] = __builtin_bit_cast(wbf16x8, qv);
+                        qf[KW - 1][j] = __builtin_bit_cast(wbf16x8, q2);
+                    } else {
+                        qf[0][j] = __builtin_bit_cast(wbf16x8, qv);
+                    }
+                }
             }
 #pragma unroll
             for (int c = 0; c < KW; ++c) {
                 const wu32x4 pv = {plo[c][0], plo[c][1], phi[c][0], phi[c][1]};
                 const wbf16x8 pf = __builtin_bit_cast(wbf16x8, pv);
 #pragma unroll
-                for (int j = 0; j < QB; ++j) {
-                    wu32x4 qv = {qlo[j][0], qlo[j][1], qhi[j][0], qhi[j][1]};
-                    if (KW == 3 && c == 0) { qv[0] &= m0[0]; qv[1] &= m0[1]; qv[2] &= m0[2]; qv[3] &= m0[3]; }
-                    if (KW == 3 && c == 2) { qv[0] &= m2[0]; qv[1] &= m2[1]; qv[2] &= m2[2]; qv[3] &= m2[3]; }
-                    const wbf16x8 qf = __builtin_bit_cast(wbf16x8, qv);
-                    acc[i * KW + c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf, acc[i * KW + c][j], 0, 0, 0);
-                }
+                for (int j = 0; j < QB; ++j)
+                    acc[i * KW + c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[c][j], acc[i * KW + c][j], 0, 0, 0);
             }
         }
     }
