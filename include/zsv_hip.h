@@ -261,6 +261,10 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
  * zero border; Hp >= H + padH, Wp >= W + padW. */
 int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, int32_t padH,
                      int32_t padW, int32_t Hp, int32_t Wp, void* out, void* stream);
+/* nn.MaxPool3d with kernel == stride (network.py:148-163: C3D's five pools) on channels-last bf16 [N][T][H][W][Cp]; padding is
+ * -inf padding (2 * pad <= kernel).  The bf16 evaluation engine of network.C3D (inference.Bf16EngineC3D). */
+int zsv_maxpool3d_bf16(const void* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT, int32_t kH, int32_t kW,
+                       int32_t pT, int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo, void* y, void* stream);
 /* [N][S][Cp] bf16 -> (N, C) fp32 mean over the S voxels (resnet.py:251-254 avgpool + flatten). */
 int zsv_meanpool_bf16(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);
 

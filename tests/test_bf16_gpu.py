@@ -306,3 +306,56 @@ def test_engines_on_other_clip_sizes(n, t, s):
     f, _ = inference.Fp32Engine(model)(x)
     assert (b * ref).sum(dim=1).min().item() >= 0.999 and (b - ref).abs().max().item() <= 2e-2
     assert (f - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("shape,kernel,pad", [((2, 64, 4, 12, 12), (1, 2, 2), (0, 0, 0)), ((1, 128, 4, 6, 6), (2, 2, 2), (0, 0, 0)),
+                                              ((3, 512, 2, 7, 7), (2, 2, 2), (0, 1, 1)), ((2, 45, 3, 5, 9), (1, 2, 2), (0, 1, 0))])
+def test_maxpool3d_channels_last_bf16(shape, kernel, pad):
+    """zsv_maxpool3d_bf16 (network.py:148-163 on the channels-last bf16 layout) against torch's MaxPool3d on the same bf16 values:
+    exact (the maximum of bf16 values is one of them)."""
+    from zeroshotvideoclassification_amd import amp
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(torch.bfloat16).float()
+    ref = F.max_pool3d(x, kernel, kernel, pad)
+    y = inference.maxpool3d_bf16(amp.ncdhw_to_cl_bf16(x.to(DEV)), shape[1], kernel, pad)
+    torch.cuda.synchronize()
+    assert tuple(y.shape[:4]) == (shape[0],) + tuple(ref.shape[2:])
+    assert torch.equal(amp.cl_to_ncdhw_f32(y, shape[1]).cpu(), ref)
+    assert float(y[..., shape[1]:].float().abs().sum()) == 0.0
+
+
+def test_c3d_bf16_engine_against_the_reference_fixture_and_the_fp32_path():
+    """network.C3D in eval mode on the bf16 engine (inference.Bf16EngineC3D: eight convolutions + five channels-last max-pools in
+    bf16, fc6 / regressor fp32): against the reference's own eval-mode embedding (tests/golden/c3d_eval.npz, N = 1) and against
+    the fp32 HIP forward on a 2x2-clip batch (bs = 2, nc = 2: the clip mean of network.py:174-176): cosine >= 0.999, 2e-2 absolute.
+    `with amp.autocast():` around an eval forward and `train.evaluate(dtype=bfloat16)` take the same route."""
+    from helpers import load_golden, make_opt
+    from zeroshotvideoclassification_amd import amp, network, train
+    g = load_golden("c3d_eval")
+    model = network.get_network(make_opt("c3d"))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=bool(g["meta_bn_jitter"])))
+    model.to(DEV).eval()
+    x = synthetic.synthetic_clips(int(g["meta_n"]), int(g["meta_frames"]), int(g["meta_size"])).to(DEV)
+    ref = torch.from_numpy(g["emb_eval_f32"]).to(DEV)
+    engine = inference.Bf16EngineC3D(model)
+    emb = engine(x)
+    assert emb.shape == ref.shape and emb.dtype == torch.float32
+    cos = (emb * ref).sum(dim=1)
+    assert cos.min().item() >= 0.999, cos
+    assert (emb - ref).abs().max().item() <= 2e-2
+    xb = torch.stack([synthetic.synthetic_clips(2, 16, 112, seed=31 + i)[:, 0] for i in range(2)]).to(DEV)     # (bs=2, nc=2, 3, 16, 112, 112)
+    with torch.no_grad():
+        plain = model(xb)
+        with amp.autocast():
+            routed = model(xb)
+    assert torch.equal(routed, inference.engine_for(model, torch.bfloat16)(xb))
+    cos = (routed * plain).sum(dim=1)
+    assert cos.min().item() >= 0.999, cos
+    assert (routed - plain).abs().max().item() <= 2e-2
+    table = synthetic.class_table(51, seed=5)
+    labels, z = synthetic.synthetic_targets(2, 51, seed=5)
+    a = train.evaluate(model, [(xb, labels, z)], table, device=torch.device(DEV), dtype=torch.bfloat16, splits=0)
+    b = train.evaluate(model, [(xb, labels, z)], table, device=torch.device(DEV), splits=0)
+    assert a["n"] == b["n"] == 2
+    with pytest.raises(RuntimeError):
+        inference.engine_for(model, torch.float32)

@@ -707,6 +707,47 @@ __global__ __launch_bounds__(256) void meanpool_bf16_kernel(const __bf16* __rest
         out[(size_t)n * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / (float)S;
 }
 
+// nn.MaxPool3d with kernel == stride on channels-last bf16 (network.py:148-163 between the C3D convolutions): one thread per
+// (output voxel, 8-channel octet), 16-byte loads; taps outside the input are skipped (-inf padding).  bf16 -> float is exact and
+// monotone, so the maximum of the floats rounds back to one of the inputs.
+__global__ void maxpool3d_bf16_kernel(const u32x4* __restrict__ x, int Ti, int Hi, int Wi, int G, int kT, int kH, int kW, int pT, int pH,
+                                      int pW, int To, int Ho, int Wo, long total, u32x4* __restrict__ y) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int o = (int)(idx % G);
+    long r = idx / G;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long n = r / To;
+    float best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+    for (int a = 0; a < kT; ++a) {
+        const int t = to * kT + a - pT;
+        if ((unsigned)t >= (unsigned)Ti) continue;
+        for (int b = 0; b < kH; ++b) {
+            const int h = ho * kH + b - pH;
+            if ((unsigned)h >= (unsigned)Hi) continue;
+            for (int c = 0; c < kW; ++c) {
+                const int w = wo * kW + c - pW;
+                if ((unsigned)w >= (unsigned)Wi) continue;
+                const u32x4 v = x[(((n * Ti + t) * Hi + h) * (long)Wi + w) * G + o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    best[2 * q] = fmaxf(best[2 * q], __builtin_bit_cast(float, v[q] << 16));
+                    best[2 * q + 1] = fmaxf(best[2 * q + 1], __builtin_bit_cast(float, v[q] & 0xffff0000u));
+                }
+            }
+        }
+    }
+    u32x4 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        out[q] = (__builtin_bit_cast(unsigned, best[2 * q]) >> 16) | (__builtin_bit_cast(unsigned, best[2 * q + 1]) & 0xffff0000u);
+    y[idx] = out;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline bool bf16_folded(const zsv_conv_desc* d) { return d->Cin <= 4; }
@@ -918,6 +959,23 @@ int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H,
     if (total * 4 >= (1L << 31)) return ZSV_E_TOO_LARGE;
     hipLaunchKernelGGL(clip_to_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, C, T,
                        H, W, padH, padW, Hp, Wp, total, (__bf16*)out);
+    return launch_status();
+}
+
+int zsv_maxpool3d_bf16(const void* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT, int32_t kH, int32_t kW,
+                       int32_t pT, int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo, void* y, void* stream) {
+    if (N <= 0 || C <= 4 || Ti <= 0 || Hi <= 0 || Wi <= 0 || kT <= 0 || kH <= 0 || kW <= 0 || pT < 0 || pH < 0 || pW < 0)
+        return ZSV_E_BAD_SHAPE;
+    if (2 * pT > kT || 2 * pH > kH || 2 * pW > kW) return ZSV_E_BAD_SHAPE;            // (every window holds at least one input voxel)
+    if (To != (Ti + 2 * pT - kT) / kT + 1 || Ho != (Hi + 2 * pH - kH) / kH + 1 || Wo != (Wi + 2 * pW - kW) / kW + 1 || To <= 0 ||
+        Ho <= 0 || Wo <= 0)
+        return ZSV_E_BAD_SHAPE;
+    if (x == nullptr || y == nullptr) return ZSV_E_NULL;
+    const int G = round_up(C, 32) / 8;
+    const long total = (long)N * To * Ho * Wo * G;
+    if ((long)N * Ti * Hi * Wi * G >= (1L << 31)) return ZSV_E_TOO_LARGE;
+    hipLaunchKernelGGL(maxpool3d_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x,
+                       Ti, Hi, Wi, G, kT, kH, kW, pT, pH, pW, To, Ho, Wo, total, (u32x4*)y);
     return launch_status();
 }
 

@@ -89,6 +89,19 @@ def meanpool_bf16(x: torch.Tensor, channels: int) -> torch.Tensor:
     return out
 
 
+def maxpool3d_bf16(x: torch.Tensor, channels: int, kernel, padding) -> torch.Tensor:
+    """nn.MaxPool3d(kernel, stride = kernel, padding) on [N][T][H][W][Cp] bf16 (network.py:148-163)."""
+    _check_bf16(x, "maxpool3d_bf16 input")
+    n, t, h, w, cp = x.shape
+    kt, kh, kw = (int(v) for v in kernel)
+    pt, ph, pw = (int(v) for v in padding)
+    to, ho, wo = (t + 2 * pt - kt) // kt + 1, (h + 2 * ph - kh) // kh + 1, (w + 2 * pw - kw) // kw + 1
+    y = torch.empty((n, to, ho, wo, cp), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().zsv_maxpool3d_bf16(x.data_ptr(), n, channels, t, h, w, kt, kh, kw, pt, ph, pw, to, ho, wo, y.data_ptr(),
+                                              ops._stream()), "zsv_maxpool3d_bf16")
+    return y
+
+
 def fold_bn(bn: Optional[nn.BatchNorm3d], conv: nn.Conv3d) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """(scale, shift) of ``bn.eval()(conv(x))``: gamma/sqrt(var+eps), beta - mean*scale (+ conv bias)."""
     bias = conv.bias.detach().float() if conv.bias is not None else None
@@ -243,6 +256,66 @@ class Bf16Engine:
         return F.normalize(emb, dim=-1), None                          # network.py:596,600
 
 
+class Bf16EngineC3D:
+    """Eval-mode ``network.C3D.forward`` (network.py:147-179) with the eight convolutions and five max-pools in bf16 on the
+    channels-last layout: ``relu(conv(x) + bias)`` is one ``zsv_conv3d_bf16_fwd`` launch per layer (bias as the epilogue's
+    shift), the pools are ``zsv_maxpool3d_bf16``; fc6 (+ ReLU), the clip mean, the regressor and the normalisation stay fp32
+    (dropout is the identity in eval mode).  Same contract as the module: ``(bs, nc, 3, T, H, W) fp32 -> (bs, 300)``."""
+
+    LAYERS = (("conv1", "pool1"), ("conv2", "pool2"), ("conv3a", None), ("conv3b", "pool3"), ("conv4a", None), ("conv4b", "pool4"),
+              ("conv5a", None), ("conv5b", "pool5"))
+
+    def __init__(self, model: nn.Module):
+        from . import network
+        model = getattr(model, "module", model)
+        if not isinstance(model, network.C3D):
+            raise RuntimeError("Bf16EngineC3D supports network.C3D")
+        if next(model.parameters()).device.type != "cuda":
+            raise RuntimeError("Bf16EngineC3D: the model must live on the MI355X HIP device (there is no CPU fallback)")
+        self.model = model
+        self.ops = []
+        for conv_name, pool_name in self.LAYERS:
+            op = _ConvOp(getattr(model, conv_name), None, True)           # network.py:147-162: relu(conv(x)), bias in the epilogue
+            pool = getattr(model, pool_name) if pool_name else None
+            if pool is not None:
+                k, st, pd = pool.kernel_size, pool.stride, pool.padding
+                k = (k,) * 3 if isinstance(k, int) else tuple(k)
+                st = k if st is None else ((st,) * 3 if isinstance(st, int) else tuple(st))
+                pd = (pd,) * 3 if isinstance(pd, int) else tuple(pd)
+                if st != k:
+                    raise RuntimeError("Bf16EngineC3D: max-pools with stride != kernel are not used by the reference")
+                pool = (k, pd)
+            self.ops.append((op, pool))
+        if not self.ops[0][0].folded:
+            raise RuntimeError("Bf16EngineC3D: conv1 must take the clip (<= 4 channels)")
+
+    @torch.no_grad()
+    def features(self, clips: torch.Tensor) -> torch.Tensor:
+        """(N, 3, T, H, W) fp32 -> (N, 8192) fp32 in the (C, T, H, W) order of ``view(-1, 8192)`` (network.py:165)."""
+        first = self.ops[0][0]
+        n, _, t, h, w = clips.shape
+        pad_h, pad_w, hp, wp = first.input_border(h, w)
+        wo = (w + 2 * pad_w - first.kernel[2]) // first.stride[2] + 1
+        x = clip_to_bf16(clips, pad_h, pad_w, hp, wp)
+        for i, (op, pool) in enumerate(self.ops):
+            x = op(x, wo=wo) if i == 0 else op(x)
+            if pool is not None:
+                x = maxpool3d_bf16(x, op.cout, pool[0], pool[1])
+        c = self.ops[-1][0].cout
+        return x[..., :c].permute(0, 4, 1, 2, 3).reshape(n, -1).float()
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor):
+        m = self.model
+        bs, nc = x.shape[:2]
+        a = self.features(x.reshape(bs * nc, *x.shape[2:]))
+        if a.shape[1] != m.fc6.in_features:
+            raise RuntimeError(f"C3D: {a.shape[1]} features reach fc6, {m.fc6.in_features} expected (16x112x112 clips)")
+        a = m.fc6(a.contiguous(), relu=True)                           # network.py:166 (dropout: identity in eval mode)
+        a = a.reshape(bs, nc, -1).mean(1).reshape(bs, -1)              # network.py:174-176
+        return F.normalize(m.regressor(a), dim=-1)                     # network.py:178-179
+
+
 class _ConvOpF32:
     """One folded fp32 convolution: w * scale and shift are formed once; ReLU and the block's residual add
     run in the convolution's epilogue (``zsv_conv3d_fwd_add``)."""
@@ -330,13 +403,18 @@ def engine_for(model: nn.Module, dtype: torch.dtype = torch.bfloat16, rebuild: b
     ``load_weights`` and ``GradientSync.broadcast_state`` write through raw pointers or ``.data`` and announce
     it there.  ``rebuild=True`` forces a rebuild (for writers this package does not know about)."""
     own = getattr(model, "module", model)
-    tensors = list(own.model.parameters()) + list(own.model.buffers())
+    from . import network
+    is_c3d = isinstance(own, network.C3D)
+    trunk = own if is_c3d else own.model
+    tensors = list(trunk.parameters()) + list(trunk.buffers())
     key = (_lib.raw_write_generation(),) + tuple((id(t), t.data_ptr(), t._version) for t in tensors)
     cache = own.__dict__.setdefault("_zsv_engines", {})
     cached = None if rebuild else cache.get(dtype)
     if cached is None or cached[0] != key:
         if dtype == torch.bfloat16:
-            engine = Bf16Engine(own)
+            engine = Bf16EngineC3D(own) if is_c3d else Bf16Engine(own)
+        elif dtype == torch.float32 and is_c3d:
+            raise RuntimeError("no folded fp32 engine for C3D (it has no BatchNorm to fold): use the module's own forward")
         elif dtype == torch.float32:
             engine = Fp32Engine(own)
         else:

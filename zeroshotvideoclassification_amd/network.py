@@ -163,6 +163,10 @@ class C3D(nn.Module):
 
     def forward(self, x):
         bs, nc, ch, t, h, w = x.shape
+        from . import amp
+        if amp.is_autocast_enabled() and x.is_cuda and not self.training and not torch.is_grad_enabled():
+            from .inference import engine_for                  # main.py:172 `with autocast():` around an eval forward
+            return engine_for(self, torch.bfloat16)(x)
         a = x.reshape(bs * nc, ch, t, h, w)
         a = self.pool1(self.conv1(a, relu=True))
         a = self.pool2(self.conv2(a, relu=True))
