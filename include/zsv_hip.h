@@ -108,6 +108,14 @@ int zsv_conv3d_dgrad_add_strided(const zsv_conv_desc* d, const float* dy, const 
 size_t zsv_conv3d_wgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The tap-validity table the stride-1 weight-gradient kernels read depends on the geometry only (input extents, kernel,
+ * padding): zsv_conv3d_wgrad rebuilds it on every call; a caller that keeps it -- zsv_conv3d_wgrad_mask_bytes(d) bytes
+ * (0: this geometry's kernel reads no table), filled once by zsv_conv3d_wgrad_mask -- passes it to zsv_conv3d_wgrad_masked
+ * and saves a launch per call (mask == NULL behaves like zsv_conv3d_wgrad).  Same results bit for bit. */
+size_t zsv_conv3d_wgrad_mask_bytes(const zsv_conv_desc* d);
+int zsv_conv3d_wgrad_mask(const zsv_conv_desc* d, void* mask, void* stream);
+int zsv_conv3d_wgrad_masked(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                            size_t workspace_bytes, const void* mask, void* stream);
 
 /* ---- convolution fed by a BatchNorm + ReLU that is never written out ------------------------------ */
 /* Conv2Plus1D runs `Conv3d(1x3x3) -> BatchNorm3d -> ReLU -> Conv3d(3x1x1)` (resnet.py:40-52).  Instead of one HBM pass

@@ -44,6 +44,9 @@ SIGNATURES = {
     "zsv_conv3d_dgrad_add_strided": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, c_size_t, _P]),
     "zsv_conv3d_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_conv3d_wgrad_mask_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "zsv_conv3d_wgrad_mask": (c_int, [POINTER(ConvDesc), _P, _P]),
+    "zsv_conv3d_wgrad_masked": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P, _P]),
     "zsv_bn_fwd_train_coeffs": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, c_float, c_float, _P, c_int32, _P,
                                         c_int32, _P, c_size_t, _P]),
     "zsv_conv3d_pre_supported": (c_int32, [POINTER(ConvDesc)]),

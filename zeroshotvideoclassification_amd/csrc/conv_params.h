@@ -263,7 +263,7 @@ int wino_fwd(const zsv_conv_desc* d, const float* x, const float* w, const float
 bool wgrad_dma_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
 size_t wgrad_dma_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* workspace, size_t workspace_bytes,
-              int* slices_out, int* cpad_out, hipStream_t stream);
+              int* slices_out, int* cpad_out, hipStream_t stream, const unsigned* vm_ext = nullptr);
 // per-voxel tap-validity words of one clip (S words; bit tap <=> the tap's input voxel is inside): used by both
 // LDS-DMA weight-gradient kernels
 int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream);
@@ -280,6 +280,6 @@ int wgrad_tring(const zsv_conv_desc* d, const float* x, const float* dy, float* 
 bool wgrad_wino_applicable(const zsv_conv_desc* d, const float* x, const float* dy);
 size_t wgrad_wino_workspace_bytes(const zsv_conv_desc* d);
 int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-               hipStream_t stream);
+               hipStream_t stream, const unsigned* vm_ext = nullptr);
 
 }  // namespace zsv

@@ -535,8 +535,42 @@ extern "C" int zsv_conv3d_wgrad_pre(const zsv_conv_desc* d, const float* x, cons
     return wgrad_tring_pre(d, x, pre_coef, coef_pitch, dy, dw, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
+static int wgrad_dispatch(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                          const unsigned* vm_ext, void* stream_);
+
 extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const float* dy, float* dw,
                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    return wgrad_dispatch(d, x, dy, dw, workspace, workspace_bytes, nullptr, stream_);
+}
+
+// The two LDS-DMA weight-gradient kernels (Winograd-form 3x3 taps, plain "same" convolutions) read a per-voxel tap-validity
+// table that depends on the geometry only; they used to rebuild it on every call (13 launches per R(2+1)D-18 step in front of
+// the kernels of the weight-gradient queue).  A caller that keeps the table passes it here.
+static bool wgrad_takes_mask(const zsv_conv_desc* d) {
+    if (conv_check(d) != ZSV_OK || t2_dense(d) || d->Cin < 16) return false;
+    if (wgrad_wino_applicable(d, nullptr, nullptr)) return true;
+    if (wgrad_tring_applicable(d, nullptr, nullptr)) return false;
+    return wgrad_dma_applicable(d, nullptr, nullptr);
+}
+
+extern "C" size_t zsv_conv3d_wgrad_mask_bytes(const zsv_conv_desc* d) {
+    return d != nullptr && wgrad_takes_mask(d) ? sizeof(unsigned) * (size_t)d->Ti * d->Hi * d->Wi : 0;
+}
+
+extern "C" int zsv_conv3d_wgrad_mask(const zsv_conv_desc* d, void* mask, void* stream_) {
+    if (d == nullptr || mask == nullptr) return ZSV_E_NULL;
+    if (!wgrad_takes_mask(d)) return ZSV_E_UNSUPPORTED;
+    return wgrad_vmask(d, (unsigned*)mask, (hipStream_t)stream_);
+}
+
+extern "C" int zsv_conv3d_wgrad_masked(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                                       size_t workspace_bytes, const void* mask, void* stream_) {
+    if (d == nullptr) return ZSV_E_NULL;
+    return wgrad_dispatch(d, x, dy, dw, workspace, workspace_bytes, wgrad_takes_mask(d) ? (const unsigned*)mask : nullptr, stream_);
+}
+
+static int wgrad_dispatch(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                          const unsigned* vm_ext, void* stream_) {
     int st = conv_check(d);
     if (st) return st;
     if (!x || !dy || !dw) return ZSV_E_NULL;
@@ -557,11 +591,11 @@ extern "C" int zsv_conv3d_wgrad(const zsv_conv_desc* d, const float* x, const fl
     const WgradPlan pl = wgrad_plan(d);
     const size_t need = zsv_conv3d_wgrad_workspace_bytes(d);
     if (!workspace || workspace_bytes < need) return ZSV_E_WORKSPACE;
-    if (wgrad_wino_applicable(d, x, dy)) return wgrad_wino(d, x, dy, dw, workspace, workspace_bytes, stream);
+    if (wgrad_wino_applicable(d, x, dy)) return wgrad_wino(d, x, dy, dw, workspace, workspace_bytes, stream, vm_ext);
     if (wgrad_tring_applicable(d, x, dy)) return wgrad_tring(d, x, dy, dw, workspace, workspace_bytes, stream);
     if (wgrad_dma_applicable(d, x, dy)) {
         int slices = 0, cpad = 0;
-        st = wgrad_dma(d, x, dy, workspace, workspace_bytes, &slices, &cpad, stream);
+        st = wgrad_dma(d, x, dy, workspace, workspace_bytes, &slices, &cpad, stream, vm_ext);
         if (st) return st;
         return slab_sum((const float*)workspace, dw, d->Cout, d->Cin, d->kT * d->kH * d->kW, cpad, slices, stream);
     }

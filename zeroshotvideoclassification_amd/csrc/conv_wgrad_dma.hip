@@ -405,7 +405,7 @@ int wgrad_vmask(const zsv_conv_desc* d, unsigned* out, hipStream_t stream) {
 
 // slabs + mask table live in `workspace`; returns the slab geometry for slab_sum_kernel
 int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* workspace, size_t workspace_bytes,
-              int* slices_out, int* cpad_out, hipStream_t stream) {
+              int* slices_out, int* cpad_out, hipStream_t stream, const unsigned* vm_ext) {
     const WgradDmaPlan pl = wgrad_dma_plan(d);
     if (!workspace || workspace_bytes < wgrad_dma_workspace_bytes(d)) return ZSV_E_WORKSPACE;
     WgradDmaParams p;
@@ -418,9 +418,14 @@ int wgrad_dma(const zsv_conv_desc* d, const float* x, const float* dy, void* wor
     p.x_elems = (long)d->N * d->Cin * p.S;
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
     float* slabs = (float*)workspace;
-    unsigned* vm = (unsigned*)((char*)workspace + align256((size_t)pl.slices * d->Cout * pl.Kp * sizeof(float)));
-    int st = wgrad_vmask(d, vm, stream);
-    if (st) return st;
+    const unsigned* vm = vm_ext;                       // (kept by the caller: zsv_conv3d_wgrad_masked)
+    int st = ZSV_OK;
+    if (vm == nullptr) {
+        unsigned* own = (unsigned*)((char*)workspace + align256((size_t)pl.slices * d->Cout * pl.Kp * sizeof(float)));
+        st = wgrad_vmask(d, own, stream);
+        if (st) return st;
+        vm = own;
+    }
     switch (pl.tm) {
         case 9: st = wgrad_dma_launch_tn<9>(pl.tn, p, pl.slices, stream, x, dy, vm, slabs); break;
         case 8: st = wgrad_dma_launch_tn<8>(pl.tn, p, pl.slices, stream, x, dy, vm, slabs); break;

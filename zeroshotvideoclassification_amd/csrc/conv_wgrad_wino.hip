@@ -361,7 +361,7 @@ static int wgrad_wino_launch(const WgradWinoParams& p, int slices, hipStream_t s
 }
 
 int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-               hipStream_t stream) {
+               hipStream_t stream, const unsigned* vm_ext) {
     const WgradWinoPlan pl = wgrad_wino_plan(d);
     if (!workspace || workspace_bytes < wgrad_wino_workspace_bytes(d)) return ZSV_E_WORKSPACE;
     WgradWinoParams p;
@@ -375,9 +375,15 @@ int wgrad_wino(const zsv_conv_desc* d, const float* x, const float* dy, float* d
     p.vm_bytes = 4u * (unsigned)p.S;
     p.tiles_m = pl.tiles_m; p.tiles_mn = pl.tiles_m * pl.tiles_n;
     float* slabs = (float*)workspace;
-    unsigned* vm = (unsigned*)((char*)workspace + ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)));
-    int st = wgrad_vmask(d, vm, stream);
-    if (st) return st;
+    // the tap-validity words depend on the geometry only: a caller that keeps them (zsv_conv3d_wgrad_masked) saves the launch
+    const unsigned* vm = vm_ext;
+    int st = ZSV_OK;
+    if (vm == nullptr) {
+        unsigned* own = (unsigned*)((char*)workspace + ww_align((size_t)pl.slices * 4 * d->Cout * pl.Kp * sizeof(float)));
+        st = wgrad_vmask(d, own, stream);
+        if (st) return st;
+        vm = own;
+    }
     const bool edge = p.S % 32 != 0 || d->Wi % 4 != 0;
     if (pl.tm == 9)
         st = edge ? wgrad_wino_launch<9, 1, true>(p, pl.slices, stream, x, dy, vm, slabs)

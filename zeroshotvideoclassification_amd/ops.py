@@ -171,6 +171,32 @@ def _queue_wgrad_join(device) -> bool:
     return True
 
 
+# ---- tap-validity tables of the weight-gradient kernels ---------------------------------------------------------------------
+# zsv_conv3d_wgrad used to rebuild its per-voxel tap-validity table on every call (13 launches per R(2+1)D-18 step at the head
+# of the weight-gradient queue's kernels).  The table depends on (input extents, kernel, padding) only: one
+# per geometry and stream is kept here (a few hundred KB each) and handed to zsv_conv3d_wgrad_masked.
+_WGRAD_MASKS = {}
+
+
+def _wgrad_mask(d: ConvDesc, device, stream: c_void_p):
+    if os.environ.get("ZSV_NO_WGRAD_MASK_CACHE"):
+        return None
+    # (the table's CONTENT depends on extents / kernel / padding only; whether a geometry's kernel reads one depends on all of it)
+    key = (torch.device(device).index, stream.value, _lib.knob_generation()) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
+    hit = _WGRAD_MASKS.get(key)
+    if hit is not None:
+        return hit if hit is not False else None
+    lib = _lib.load()
+    nbytes = int(lib.zsv_conv3d_wgrad_mask_bytes(byref(d)))
+    if nbytes == 0:
+        _WGRAD_MASKS[key] = False                       # this geometry's kernel reads no table
+        return None
+    mask = torch.empty(nbytes, dtype=torch.uint8, device=device)      # (allocated under the stream the launch runs on)
+    _lib.check(lib.zsv_conv3d_wgrad_mask(byref(d), mask.data_ptr(), stream), "zsv_conv3d_wgrad_mask")
+    _WGRAD_MASKS[key] = mask
+    return mask
+
+
 class KernelTimer:
     """Optional HIP-event timing of one kernel family on one geometry (used by bench.py for the
     live roofline figure): events are recorded on the launch stream around matching launches;
@@ -582,8 +608,9 @@ class _Conv3d(Function):
                 def launch(stream):
                     out = torch.empty_like(weight)
                     ws = _workspace(nbytes, dy.device)
-                    _lib.check(lib.zsv_conv3d_wgrad(byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(), _ptr(ws), nbytes,
-                                                    stream), "zsv_conv3d_wgrad")
+                    mask = _wgrad_mask(d, dy.device, stream)         # geometry-only table, built once per (geometry, stream)
+                    _lib.check(lib.zsv_conv3d_wgrad_masked(byref(d), x.data_ptr(), dy.data_ptr(), out.data_ptr(), _ptr(ws), nbytes,
+                                                           _ptr(mask), stream), "zsv_conv3d_wgrad")
                     return out
 
                 dw = _on_wgrad_stream(launch, (x, dy), weight)
