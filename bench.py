@@ -501,6 +501,7 @@ def extra_train_bf16(dev, steps=10, warmup=6):
     step()
     torch.cuda.synchronize()
     run_queued(step, max(warmup - 1, 1))
+    settle = settle_allocator(step, steps, dev, max_rounds=3, label="extra.train_bf16 ")    # (many block sizes on two streams: the pool settles late)
     geometry = dict(S1_GEOMETRY, N=CLIPS_PER_GPU)
     timer = ops.KernelTimer("conv_bf16_fwd", geometry)
     ops.KERNEL_TIMER = timer
@@ -515,7 +516,7 @@ def extra_train_bf16(dev, steps=10, warmup=6):
            "value": round(value, 2), "unit": "clips/s", "steps": steps, "warmup": warmup, "dtype": "bf16 (fp32 accumulate)",
            "ms_per_step": round(1e3 * wall / steps, 3), "median_step_ms_on_device": round(statistics.median(dev_ms), 3),
            "host_queued_all_after_ms": round(1e3 * host[-1], 2), "host_lead_steps": behind,
-           "allocator_in_timed_region": allocator_delta(a, b), "final_loss": float(loss.item()),
+           "allocator_in_timed_region": allocator_delta(a, b), "allocator_settle_rounds": settle, "final_loss": float(loss.item()),
            "loss_scale": float(scaler.get_scale()) if hasattr(scaler, "get_scale") else None,
            "step_roofline": {"bf16_flop_frac_algorithmic": round(value * 242.5e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
                              "note": "242.5 GFLOP/clip (SURVEY 8d) against the 2.5 PFLOP/s dense bf16 matrix peak; the step is bound by HBM "
