@@ -285,14 +285,17 @@ int zsv_meanpool_bf16(const void* x, int32_t N, int32_t S, int32_t C, float* out
  *   y = relu?(gamma*(z-mean)*invstd + beta (+ residual)) rounded once to bf16; save_mean / save_invstd (C floats) for backward.
  * zsv_bn_cl_bwd: g = dy * (y > 0) when relu_mask (y = the forward's output), dgamma / dbeta (C floats, may be NULL),
  *   dz (bf16) = the BatchNorm input gradient; g_out (may be NULL) receives g itself -- the gradient of a residual branch.
+ *   save_coef (may be NULL): 2 * Cp floats, the forward's scale a and shift b per (padded) channel.  Passed back as `fwd_coef`
+ *   with y == NULL (no residual in the forward) the backward recomputes the ReLU mask as fma(z, a, b) > 0 -- exactly what the
+ *   forward rounded to y -- and does not read the saved output at all (4 of its 14 bytes per element).
  * workspace: zsv_bn_cl_workspace_bytes(R, C) bytes (0 = unsupported shape). */
 size_t zsv_bn_cl_workspace_bytes(int64_t R, int32_t C);
 int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
-                        float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
+                        float* save_mean, float* save_invstd, float* save_coef, void* workspace, size_t workspace_bytes, void* stream);
 int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
-                  const float* save_invstd, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta, void* workspace,
-                  size_t workspace_bytes, void* stream);
+                  const float* save_invstd, const float* fwd_coef, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta,
+                  void* workspace, size_t workspace_bytes, void* stream);
 /* Weight gradient of a stride-1 "same" convolution from channels-last bf16 operands (x [N][T][H][W][CinP], dz
  * [N][T][H][W][CoutP]) with fp32 accumulation: dw (Cout, Cin, kT, kH, kW) fp32 -- aten::convolution_backward's weight
  * gradient under autocast (resnet.py:40-52 1x3x3 / 3x1x1, resnet.py:23-30 3x3x3).  The workspace holds per-slice partial

@@ -105,6 +105,19 @@ def test_batchnorm_channels_last_forward_backward(shape, relu, res):
         gm = from_cl(g_cl, c)
         expect = dy * (y > 0) if relu else dy
         assert torch.equal(gm, expect)
+    if relu and not res:
+        # the training path's form for a unit without a residual: the mask recomputed from z and the forward's scale / shift rows
+        # (fma(z, a, b) > 0 is what the forward rounded to y): the saved output is not read, the results are the same bits
+        bn2 = torch.nn.BatchNorm3d(c).to(DEV).train()
+        bn2.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+        bn2.float()
+        with torch.no_grad():
+            bn2.running_mean.copy_(bn.running_mean); bn2.running_var.copy_(bn.running_var)
+        y2, mean2, invstd2, coef = amp.bn_cl_fwd_train(z_cl, bn2, None, True, want_coef=True)
+        assert torch.equal(y2, y_cl) and tuple(coef.shape) == (2, z_cl.shape[-1])
+        dz2, _, dgamma2, dbeta2 = amp.bn_cl_bwd(dy_cl, None, z_cl, bn2, mean2, invstd2, True, want_g=False, fwd_coef=coef)
+        torch.cuda.synchronize()
+        assert torch.equal(dz2, dz_cl) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
 
 
 @pytest.mark.parametrize("geom", [

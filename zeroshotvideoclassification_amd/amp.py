@@ -74,8 +74,9 @@ def _rows(t: torch.Tensor) -> int:
     return t.numel() // t.shape[-1]
 
 
-def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torch.Tensor], relu: bool):
-    """Train-mode ``BatchNorm3d`` (+ residual) (+ ReLU) on a channels-last bf16 tensor.  Returns (y, mean, invstd)."""
+def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torch.Tensor], relu: bool, want_coef: bool = False):
+    """Train-mode ``BatchNorm3d`` (+ residual) (+ ReLU) on a channels-last bf16 tensor.  Returns (y, mean, invstd), or
+    (y, mean, invstd, coef) with ``want_coef``: the (2, Cp) scale / shift rows the backward recomputes the ReLU mask from."""
     lib = _lib.load()
     c = bn.num_features
     r = _rows(z)
@@ -86,25 +87,29 @@ def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torc
     y = torch.empty_like(z)
     mean = torch.empty(c, dtype=torch.float32, device=z.device)
     invstd = torch.empty(c, dtype=torch.float32, device=z.device)
+    coef = torch.empty((2, z.shape[-1]), dtype=torch.float32, device=z.device) if want_coef else None
     track = bn.track_running_stats and bn.running_mean is not None
     momentum = 0.1 if bn.momentum is None else float(bn.momentum)
     _lib.check(lib.zsv_bn_cl_fwd_train(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
                                        bn.running_mean.data_ptr() if track else None,
                                        bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
-                                       1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
-                                       ops._stream()), "zsv_bn_cl_fwd_train")
+                                       1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ops._ptr(coef), ws.data_ptr(),
+                                       nbytes, ops._stream()), "zsv_bn_cl_fwd_train")
     if track:
         pending = getattr(_state, "nbt_pending", None)
         if pending is not None:
             pending.append(bn.num_batches_tracked)       # one _foreach_add_ at the end of the trunk instead of 37 one-element launches
         else:
             bn.num_batches_tracked.add_(1)
+    if want_coef:
+        return y, mean, invstd, coef
     return y, mean, invstd
 
 
 def bn_cl_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], z: torch.Tensor, bn: nn.BatchNorm3d, mean, invstd, relu: bool,
-              want_g: bool):
-    """Returns (dz, g or None, dgamma, dbeta)."""
+              want_g: bool, fwd_coef: Optional[torch.Tensor] = None):
+    """Returns (dz, g or None, dgamma, dbeta).  With ``fwd_coef`` (the forward's scale / shift rows; only valid when the forward
+    had no residual) the ReLU mask is recomputed from z and the saved output ``y`` is not read."""
     lib = _lib.load()
     c = bn.num_features
     r = _rows(z)
@@ -114,8 +119,10 @@ def bn_cl_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], z: torch.Tensor, bn: 
     g = torch.empty_like(z) if want_g else None
     dgamma = torch.empty(c, dtype=torch.float32, device=z.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=z.device)
-    _lib.check(lib.zsv_bn_cl_bwd(dy.data_ptr(), ops._ptr(y) if relu else None, z.data_ptr(), r, c, ops._ptr(bn.weight),
-                                 mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0, dz.data_ptr(), ops._ptr(g),
+    use_coef = relu and fwd_coef is not None
+    _lib.check(lib.zsv_bn_cl_bwd(dy.data_ptr(), ops._ptr(y) if (relu and not use_coef) else None, z.data_ptr(), r, c, ops._ptr(bn.weight),
+                                 mean.data_ptr(), invstd.data_ptr(), ops._ptr(fwd_coef) if use_coef else None, 1 if relu else 0,
+                                 dz.data_ptr(), ops._ptr(g),
                                  dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, ops._stream()), "zsv_bn_cl_bwd")
     return dz, g, dgamma, dbeta
 
@@ -175,7 +182,7 @@ class _Unit:
 
 
 class _Record:
-    __slots__ = ("unit", "x", "z", "y", "mean", "invstd", "desc", "has_res", "clips")
+    __slots__ = ("unit", "x", "z", "y", "mean", "invstd", "desc", "has_res", "clips", "coef")
 
 
 def _units(mods) -> List[_Unit]:
@@ -226,10 +233,14 @@ class Bf16TrainPath:
         z = conv_bf16(d, x, blob, None, False)
         if mark is not None:
             timer.stop(mark)
-        y, mean, invstd = bn_cl_fwd_train(z, u.bn, residual, u.relu)
+        # (a unit with ReLU and no residual keeps its scale / shift rows: the backward recomputes the mask from z, y is not read there)
+        keep_coef = tape is not None and u.relu and residual is None
+        out = bn_cl_fwd_train(z, u.bn, residual, u.relu, want_coef=keep_coef)
+        y, mean, invstd = out[0], out[1], out[2]
         if tape is not None:
             r = _Record()
             r.unit, r.x, r.z, r.y, r.mean, r.invstd, r.desc, r.has_res, r.clips = u, x, z, y, mean, invstd, d, residual is not None, clips
+            r.coef = out[3] if keep_coef else None
             tape.append(r)
         return y
 
@@ -369,7 +380,7 @@ class Bf16TrainPath:
             r = tape[idx]
             idx -= 1
             u = r.unit
-            dz, g, dgamma, dbeta = bn_cl_bwd(dy, r.y, r.z, u.bn, r.mean, r.invstd, u.relu, want_g)
+            dz, g, dgamma, dbeta = bn_cl_bwd(dy, r.y, r.z, u.bn, r.mean, r.invstd, u.relu, want_g, fwd_coef=r.coef)
             grads[id(u.bn.weight)] = dgamma
             grads[id(u.bn.bias)] = dbeta
             if need_weight_grads and u.conv.weight.requires_grad:

@@ -51,6 +51,7 @@ struct Bf16Params {
     int P;                     // output voxels N*To*Ho*Wo
     int tiles_m, tiles_n;
     int relu;
+    int cc_outer;              // shared-image kernel: walk the K chunks outermost (image rows of one chunk stay in L2 across the kh groups)
 };
 
 // 16-byte slot swizzle of a 64-byte LDS row: ds_read_b128 serves lanes in the groups
@@ -437,7 +438,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
         for (int k = 0; k < NAW; ++k) __builtin_amdgcn_global_load_lds(wq + a_off[k], (lds_ptr_t)(base + a_dst[k]), 16, 0, 0);
         if (++a_kw == KW) {
             a_kw = 0;
-            if (++a_cc == prm.nchunk) { a_cc = 0; ++a_grp; }
+            if (prm.cc_outer) {
+                if (++a_grp == prm.kT * prm.kH) { a_grp = 0; ++a_cc; }
+            } else if (++a_cc == prm.nchunk) { a_cc = 0; ++a_grp; }
         }
     };
     int b_kt = 0, b_kh = 0, b_cc = 0;                // walk of the B image issue
@@ -450,7 +453,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
             const __bf16* ptr = (unsigned)src < (unsigned)prm.P ? X + ((size_t)src * prm.sW + b_cc * 32 + srcslot) : zero;
             __builtin_amdgcn_global_load_lds(ptr, (lds_ptr_t)(base + i_dst[k]), 16, 0, 0);
         }
-        if (++b_cc == prm.nchunk) {
+        if (prm.cc_outer) {
+            if (++b_kh == prm.kH) {
+                b_kh = 0;
+                if (++b_kt == prm.kT) { b_kt = 0; ++b_cc; }
+            }
+        } else if (++b_cc == prm.nchunk) {
             b_cc = 0;
             if (++b_kh == prm.kH) { b_kh = 0; ++b_kt; }
         }
@@ -501,8 +509,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
             abuf = abuf == 2 ? 0 : abuf + 1;
             abuf2 = abuf2 == 2 ? 0 : abuf2 + 1;
         }
-        tap += KW;
-        if (img % prm.nchunk != prm.nchunk - 1) tap -= KW;      // same (kt,kh) group, next chunk
+        if (prm.cc_outer) {
+            tap += KW;
+            if (tap == prm.kT * prm.kH * KW) tap = 0;           // next chunk: the groups start over
+        } else {
+            tap += KW;
+            if (img % prm.nchunk != prm.nchunk - 1) tap -= KW;  // same (kt,kh) group, next chunk
+        }
     }
     epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
 #endif
@@ -919,6 +932,9 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.P = d->N * p.ToHoWo;
     p.relu = fuse_relu ? 1 : 0;
+    // (with >= 3 chunks of 32 input channels the image rows of all chunks of a (kt,kh) group no longer fit the XCD's L2 next to the
+    // other workgroups': 1.19 GB fetched for 353 MB of dz on layer1's input gradient, profiles/r04_bf16_training_kernels_pmc.json)
+    p.cc_outer = (p.nchunk >= 3 && ZSV_KNOB(BF16_GROUP_OUTER) == nullptr) ? 1 : 0;
     const __bf16* wp = (const __bf16*)blob;
     const float* shift = (const float*)((const char*)blob + (size_t)p.nq * p.Mp * 32 * 2);
     const __bf16* xb = (const __bf16*)x;

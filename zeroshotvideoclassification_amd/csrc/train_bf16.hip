@@ -52,15 +52,22 @@ struct ClShape {
     long rows_per_block;
 };
 
-// MODE 0: sums of (z, z*z).  MODE 1: sums of (g, g*z) with g = dy, MODE 2: the same with g = dy * (y > 0).
+// MODE 0: sums of (z, z*z).  MODE 1: sums of (g, g*z) with g = dy, MODE 2: the same with g = dy * (y > 0), MODE 3: the same
+// with the mask recomputed from z and the forward's coefficients (fma(z, a, b) > 0: what the forward rounded to y -- a positive
+// fp32 never rounds to a bf16 zero -- so the saved output need not be read: 4 of the backward's 14 bytes per element).
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_cl_reduce_kernel(ClShape sh, const u32x4v* __restrict__ z, const u32x4v* __restrict__ dy,
-                                                           const u32x4v* __restrict__ y, float* __restrict__ partial) {
+                                                           const u32x4v* __restrict__ y, const float* __restrict__ fwd_coef,
+                                                           float* __restrict__ partial) {
     extern __shared__ float red[];                 // [RL][2][Cp]
     const int o = threadIdx.x % sh.G, rl = threadIdx.x / sh.G;
-    float s0[8], s1[8];
+    float s0[8], s1[8], fa[8], fb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s0[j] = s1[j] = 0.f;
+    if (MODE == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = fwd_coef[o * 8 + j]; fb[j] = fwd_coef[sh.Cp + o * 8 + j]; }
+    }
     const long row0 = (long)blockIdx.x * sh.rows_per_block;
     long row_end = row0 + sh.rows_per_block;
     if (row_end > sh.R) row_end = sh.R;
@@ -80,6 +87,10 @@ __global__ __launch_bounds__(256) void bn_cl_reduce_kernel(ClShape sh, const u32
                     unpack8(__builtin_nontemporal_load(y + idx), yv);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+                }
+                if (MODE == 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gv[j] = fmaf(zv[j], fa[j], fb[j]) > 0.f ? gv[j] : 0.f;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s0[j] += gv[j]; s1[j] = fmaf(gv[j], zv[j], s1[j]); }
@@ -106,6 +117,7 @@ __device__ __forceinline__ void partial_sums_16(const float* __restrict__ partia
     const int slice = threadIdx.x >> 4, cl = threadIdx.x & 15;
     double a = 0.0, b = 0.0;
     if (c < Cp) {
+#pragma unroll 8
         for (int blk = slice; blk < nb; blk += 16) {
             a += (double)partial[(size_t)blk * 2 * Cp + c];
             b += (double)partial[(size_t)blk * 2 * Cp + Cp + c];
@@ -202,16 +214,22 @@ __global__ __launch_bounds__(256) void bn_cl_bwd_finalize_kernel(const float* __
     coef[2 * Cp + c] = (float)Cc;
 }
 
-// dz = A*g + B*z + C with g = dy (* (y > 0)); GOUT: also store g (the residual branch's gradient)
-template <bool MASK, bool GOUT>
+// dz = A*g + B*z + C with g = dy (* mask); MASK 0: none, 1: y > 0 (saved output), 2: fma(z, a, b) > 0 (forward coefficients);
+// GOUT: also store g (the residual branch's gradient)
+template <int MASK, bool GOUT>
 __global__ __launch_bounds__(256) void bn_cl_bwd_apply_kernel(ClShape sh, const u32x4v* __restrict__ dy, const u32x4v* __restrict__ y,
                                                               const u32x4v* __restrict__ z, const float* __restrict__ coef,
-                                                              u32x4v* __restrict__ dz, u32x4v* __restrict__ gout) {
+                                                              const float* __restrict__ fwd_coef, u32x4v* __restrict__ dz,
+                                                              u32x4v* __restrict__ gout) {
     const int o = threadIdx.x % sh.G, rl = threadIdx.x / sh.G;
     if (rl >= sh.RL) return;
-    float A[8], B[8], Cc[8];
+    float A[8], B[8], Cc[8], fa[8], fb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { A[j] = coef[o * 8 + j]; B[j] = coef[sh.Cp + o * 8 + j]; Cc[j] = coef[2 * sh.Cp + o * 8 + j]; }
+    if (MASK == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { fa[j] = fwd_coef[o * 8 + j]; fb[j] = fwd_coef[sh.Cp + o * 8 + j]; }
+    }
     const long row0 = (long)blockIdx.x * sh.rows_per_block;
     long row_end = row0 + sh.rows_per_block;
     if (row_end > sh.R) row_end = sh.R;
@@ -220,11 +238,15 @@ __global__ __launch_bounds__(256) void bn_cl_bwd_apply_kernel(ClShape sh, const 
         float gv[8], zv[8];
         unpack8(__builtin_nontemporal_load(dy + idx), gv);
         unpack8(__builtin_nontemporal_load(z + idx), zv);
-        if (MASK) {
+        if (MASK == 1) {
             float yv[8];
             unpack8(__builtin_nontemporal_load(y + idx), yv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        }
+        if (MASK == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = fmaf(zv[j], fa[j], fb[j]) > 0.f ? gv[j] : 0.f;
         }
         if (GOUT) gout[idx] = pack8(gv);
         float dv[8];
@@ -330,7 +352,7 @@ size_t zsv_bn_cl_workspace_bytes(int64_t R, int32_t C) {
 
 int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
-                        float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+                        float* save_mean, float* save_invstd, float* save_coef, void* workspace, size_t workspace_bytes, void* stream) {
     ClShape sh;
     int nb = 0;
     const int st = cl_shape(R, C, &sh, &nb);
@@ -339,9 +361,9 @@ int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t 
     if (workspace_bytes < cl_workspace_bytes(sh, nb)) return ZSV_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
-    float* coef = partial + (size_t)nb * 2 * sh.Cp;
+    float* coef = save_coef ? save_coef : partial + (size_t)nb * 2 * sh.Cp;       // [2][Cp]: kept by the caller for the backward's mask
     const size_t lds = (size_t)sh.RL * 2 * sh.Cp * sizeof(float);
-    hipLaunchKernelGGL((bn_cl_reduce_kernel<0>), dim3(nb), dim3(256), lds, s, sh, (const u32x4v*)z, nullptr, nullptr, partial);
+    hipLaunchKernelGGL((bn_cl_reduce_kernel<0>), dim3(nb), dim3(256), lds, s, sh, (const u32x4v*)z, nullptr, nullptr, nullptr, partial);
     hipLaunchKernelGGL(bn_cl_fwd_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, partial, nb, C, sh.Cp, (long)R, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, coef);
     const u32x4v* zz = (const u32x4v*)z;
@@ -358,32 +380,32 @@ int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t 
 }
 
 int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
-                  const float* save_invstd, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta, void* workspace,
-                  size_t workspace_bytes, void* stream) {
+                  const float* save_invstd, const float* fwd_coef, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta,
+                  void* workspace, size_t workspace_bytes, void* stream) {
     ClShape sh;
     int nb = 0;
     const int st = cl_shape(R, C, &sh, &nb);
     if (st != ZSV_OK) return st;
     if (!dy || !z || !dz || !save_mean || !save_invstd || !workspace) return ZSV_E_NULL;
-    if (relu_mask && !y) return ZSV_E_NULL;
+    if (relu_mask && !y && !fwd_coef) return ZSV_E_NULL;
     if (workspace_bytes < cl_workspace_bytes(sh, nb)) return ZSV_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partial = (float*)workspace;
     float* coef = partial + (size_t)nb * 2 * sh.Cp;
     const size_t lds = (size_t)sh.RL * 2 * sh.Cp * sizeof(float);
     const u32x4v *gg = (const u32x4v*)dy, *yy = (const u32x4v*)y, *zz = (const u32x4v*)z;
-    if (relu_mask) hipLaunchKernelGGL((bn_cl_reduce_kernel<2>), dim3(nb), dim3(256), lds, s, sh, zz, gg, yy, partial);
-    else hipLaunchKernelGGL((bn_cl_reduce_kernel<1>), dim3(nb), dim3(256), lds, s, sh, zz, gg, yy, partial);
+    const int mask = !relu_mask ? 0 : (y ? 1 : 2);          // 1: the saved output, 2: recomputed from z and the forward's coefficients
+    if (mask == 1) hipLaunchKernelGGL((bn_cl_reduce_kernel<2>), dim3(nb), dim3(256), lds, s, sh, zz, gg, yy, fwd_coef, partial);
+    else if (mask == 2) hipLaunchKernelGGL((bn_cl_reduce_kernel<3>), dim3(nb), dim3(256), lds, s, sh, zz, gg, yy, fwd_coef, partial);
+    else hipLaunchKernelGGL((bn_cl_reduce_kernel<1>), dim3(nb), dim3(256), lds, s, sh, zz, gg, yy, fwd_coef, partial);
     hipLaunchKernelGGL(bn_cl_bwd_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, partial, nb, C, sh.Cp, (long)R, gamma,
                        save_mean, save_invstd, dgamma, dbeta, coef);
     u32x4v *dd = (u32x4v*)dz, *go = (u32x4v*)g_out;
-    if (relu_mask) {
-        if (g_out) hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<true, true>), dim3(nb), dim3(256), 0, s, sh, gg, yy, zz, coef, dd, go);
-        else hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, sh, gg, yy, zz, coef, dd, go);
-    } else {
-        if (g_out) hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<false, true>), dim3(nb), dim3(256), 0, s, sh, gg, yy, zz, coef, dd, go);
-        else hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<false, false>), dim3(nb), dim3(256), 0, s, sh, gg, yy, zz, coef, dd, go);
-    }
+#define ZSV_BWD_APPLY(M, G) hipLaunchKernelGGL((bn_cl_bwd_apply_kernel<M, G>), dim3(nb), dim3(256), 0, s, sh, gg, yy, zz, coef, fwd_coef, dd, go)
+    if (mask == 1) { if (g_out) ZSV_BWD_APPLY(1, true); else ZSV_BWD_APPLY(1, false); }
+    else if (mask == 2) { if (g_out) ZSV_BWD_APPLY(2, true); else ZSV_BWD_APPLY(2, false); }
+    else { if (g_out) ZSV_BWD_APPLY(0, true); else ZSV_BWD_APPLY(0, false); }
+#undef ZSV_BWD_APPLY
     return launch_status();
 }
 
