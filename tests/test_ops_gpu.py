@@ -853,9 +853,10 @@ def test_batchnorm_relu_folded_into_the_temporal_convolution(n, cin, cout, thw, 
 
 
 @pytest.mark.parametrize("n,cin,cout,thw", [(4, 144, 64, (16, 56, 56)), (22, 230, 128, (8, 28, 28)), (6, 48, 144, (16, 40, 40)),
-                                            (5, 64, 45, (16, 48, 48)), (22, 128, 256, (4, 14, 14)), (3, 20, 70, (8, 60, 60))],
+                                            (5, 64, 45, (16, 48, 48)), (22, 128, 256, (4, 14, 14)), (3, 20, 70, (8, 60, 60)),
+                                            (3, 144, 64, (32, 28, 28)), (5, 48, 144, (32, 22, 22))],
                          ids=["t1_like", "layer2_ragged_last_segment", "three_row_tiles", "ragged_rows_45", "layer3_t4_partial_tiles",
-                              "ragged_k_20_channels"])
+                              "ragged_k_20_channels", "t32_two_frame_quads_per_wave", "t32_ragged_last_segment_three_row_tiles"])
 def test_conv3d_temporal_winograd_path(n, cin, cout, thw, monkeypatch):
     """Temporal 3x1x1 stride-1 convolutions through the Winograd-along-T kernels (conv_winot4_kernel, F(4,3), and conv_winot_kernel,
     F(2,3)): forward (plain, with the BatchNorm partial statistics) and input gradient (plain, with the fused shortcut add) against

@@ -1120,9 +1120,20 @@ __global__ __launch_bounds__(256, 2) void conv_winot4_kernel(WinoParams prm, con
 
     const int g = lane >> 4, r16 = lane & 15;
     // this wave's 16-quad block: block b = wave = (frame quad b / (PW/16), 16-position group b % (PW/16))
-    const int groups_log2 = prm.pw_log2 - 4;                       // 16-position groups per frame: PW / 16
-    const int tq = wave >> groups_log2;
-    const int col = 16 * (wave - (tq << groups_log2)) + r16;       // position inside the tile
+    // quad q = 16 * wave + r16 of the tile's 64 = (frame quad q / PW, position q % PW).  With PW >= 16 (T <= 16) a wave's 16
+    // quads share their frame quad (wave-uniform: scalar registers, as before); with T = 32 (PW = 8: the 32-frame clips of
+    // BASELINE config 5 in fp32) a wave holds two frame quads of 8 positions and the frame quad is a per-lane value
+    int tq, col;
+    if (prm.pw_log2 >= 4) {
+        const int groups_log2 = prm.pw_log2 - 4;                   // 16-position groups per frame: PW / 16
+        const int tqw = wave >> groups_log2;
+        tq = tqw;
+        col = 16 * (wave - (tqw << groups_log2)) + r16;            // position inside the tile
+    } else {
+        const int q = 16 * wave + r16;
+        tq = q >> prm.pw_log2;
+        col = q & (PW - 1);
+    }
     const bool zero_d0 = tq == 0;                                   // frame -1
     const bool zero_d5 = 4 * tq + 4 >= T;                           // frame T
     const int a_frag = r16 * 16 + ((g ^ (((r16 >> 2) & 1) << 1)) << 2);
@@ -1403,7 +1414,9 @@ static int winot_segs(const zsv_conv_desc* d) {
 }
 static bool winot_geometry(const zsv_conv_desc* d, int M) {
     if (ZSV_KNOB(NO_WINO) || ZSV_KNOB(NO_WINOT) || !winot_shape(d)) return false;
-    if ((d->Ti != 4 && d->Ti != 8 && d->Ti != 16) || (d->Hi * d->Wi) % 4 != 0 || d->Cin < 16 || d->Cout < 16) return false;
+    // T = 32 (round 4): only the F(4,3) kernel takes it (a wave holds two frame quads of 8 positions)
+    const bool t32 = d->Ti == 32 && ZSV_KNOB(WINOT_NO_F43) == nullptr && ZSV_KNOB(WINOT_NO_T32) == nullptr;
+    if ((d->Ti != 4 && d->Ti != 8 && d->Ti != 16 && !t32) || (d->Hi * d->Wi) % 4 != 0 || d->Cin < 16 || d->Cout < 16) return false;
     const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
     if ((long)d->Cout * P >= (1L << 29) || (long)d->Cin * P >= (1L << 29)) return false;
     const int bm = 16 * wino_tm(M);
@@ -1536,7 +1549,7 @@ static int winot_run(const zsv_conv_desc* d, int M, int C, const float* in, cons
     p.P = d->N * p.S;
     p.in_bytes = 4u * (unsigned)((long)d->N * C * p.S);
     p.PW = 256 / d->Ti;
-    p.pw_log2 = d->Ti == 4 ? 6 : d->Ti == 8 ? 5 : 4;
+    p.pw_log2 = d->Ti == 4 ? 6 : d->Ti == 8 ? 5 : d->Ti == 16 ? 4 : 3;
     p.out_bytes = 4u * (unsigned)((long)d->N * M * p.S);
     p.segs = winot_segs(d);
     p.tiles_m = p.Mp / bm;

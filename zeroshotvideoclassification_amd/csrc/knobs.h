@@ -12,6 +12,7 @@
     X(BF16_NO_SAME) \
     X(BF16_NO_TSAME) \
     X(BF16_NO_SAME64) \
+    X(WINOT_NO_T32) \
     X(BF16_GROUP_OUTER) \
     X(BF16_NO_WGRAD) \
     X(NO_DGRAD_S2) \
