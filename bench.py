@@ -535,6 +535,42 @@ def extra_train_bf16(dev, steps=10, warmup=6):
     return out
 
 
+def extra_train_bf16_c3d(dev, steps=10, warmup=4):
+    """The mixed-precision step for BASELINE configs[3]'s network: C3D, 22 clips, amp.Bf16TrainPathC3D (never the headline)."""
+    from types import SimpleNamespace
+    from zeroshotvideoclassification_amd import network, optim, synthetic, train
+    model = network.get_network(SimpleNamespace(network="c3d", fixconvs=False, nopretrained=False))
+    model.load_state_dict(synthetic.keyed_state_dict(model.state_dict(), seed=0))
+    model.to(dev).train()
+    criterion = torch.nn.MSELoss().to(dev)
+    optimizer = optim.FusedAdam(model.parameters(), lr=1e-3)
+    scaler = optim.LossScaler(init_scale=2.0 ** 16)
+    x = synthetic.synthetic_clips(CLIPS_PER_GPU, FRAMES, SIZE).to(dev)
+    _, z = synthetic.synthetic_targets(CLIPS_PER_GPU)
+    z = z.to(dev)
+    pacer = train.StepPacer(pacer_depth()) if pacer_depth() > 0 else None
+
+    def step():
+        return train.train_step(model, optimizer, criterion, x, z, scaler=scaler, pacer=pacer, autocast=True)
+
+    step()
+    torch.cuda.synchronize()
+    run_queued(step, max(warmup - 1, 1))
+    settle = settle_allocator(step, steps, dev, max_rounds=3, label="extra.train_bf16_c3d ")
+    a = allocator_snapshot(dev)
+    wall, host, dev_ms, behind, (_, loss) = run_queued(step, steps)
+    b = allocator_snapshot(dev)
+    value = CLIPS_PER_GPU * steps / wall
+    return {"workload": f"c3d MIXED-PRECISION training step (autocast(fwd + MSE) + scaled bwd + unscale / inf check + Adam), {CLIPS_PER_GPU} clips "
+                        f"3x{FRAMES}x{SIZE}x{SIZE}: convolutions + max-pools forward and backward in bf16, fc6 / regressor / loss fp32 (never the headline)",
+            "value": round(value, 2), "unit": "clips/s", "steps": steps, "warmup": warmup, "dtype": "bf16 (fp32 accumulate)",
+            "ms_per_step": round(1e3 * wall / steps, 3), "median_step_ms_on_device": round(statistics.median(dev_ms), 3),
+            "host_lead_steps": behind, "allocator_in_timed_region": allocator_delta(a, b), "allocator_settle_rounds": settle,
+            "final_loss": float(loss.item()),
+            "step_roofline": {"bf16_flop_frac_algorithmic": round(value * 3 * 77.06e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+                              "note": "3 x 77.06 GFLOP/clip (forward + both gradients; SURVEY section 6) against the 2.5 PFLOP/s dense bf16 peak"}}
+
+
 def extra_eval_t32_bf16(dev, batches=6, repeats=5):
     """BASELINE.json configs[4] per GPU: the reference's ``evaluate()`` protocol (main.py:224-313) on 32-frame clips
     with the bf16 engine: eval forward + cosine nearest class + the 10 half-class splits, three class tables."""
@@ -792,7 +828,8 @@ def main():
             del model, optimizer, x
             torch.cuda.empty_cache()
             extra = {}
-            for name, fn in (("c3d", extra_c3d), ("eval_t32_bf16", extra_eval_t32_bf16), ("train_bf16", extra_train_bf16)):
+            for name, fn in (("c3d", extra_c3d), ("eval_t32_bf16", extra_eval_t32_bf16), ("train_bf16", extra_train_bf16),
+                             ("train_bf16_c3d", extra_train_bf16_c3d)):
                 try:
                     log(f"extra.{name} ...")
                     extra[name] = fn(dev)

@@ -304,6 +304,15 @@ int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32
 size_t zsv_conv3d_bf16_wgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_bf16_wgrad(const zsv_conv_desc* d, const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* C3D's half of the mixed-precision step (network.py:147-163 under autocast: `relu(conv(x) + bias)` and MaxPool3d backward):
+ * zsv_maxpool3d_bf16_bwd: gradient of zsv_maxpool3d_bf16 -- dy goes to each window's FIRST maximum in (t, h, w) order per channel
+ *   (aten::max_pool3d_with_indices' argmax, recomputed from the saved input x), zero elsewhere;
+ * zsv_relu_bias_bwd_cl: g = dy * (y > 0) in bf16 and dbias[c] = sum of g over the R rows (fp32 / fp64 accumulation); workspace =
+ *   zsv_bn_cl_workspace_bytes(R, C). */
+int zsv_maxpool3d_bf16_bwd(const void* dy, const void* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT, int32_t kH,
+                           int32_t kW, int32_t pT, int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo, void* dx, void* stream);
+int zsv_relu_bias_bwd_cl(const void* dy, const void* y, int64_t R, int32_t C, void* g_out, float* dbias, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* layout converters between the two activation layouts: [N][S][Cp] bf16 <-> (N, C, S) fp32 (C > 4; pad channels read as /
  * written with zero): they hand a bf16 tensor to the fp32 NCDHW kernels (weight gradients of the mixed-precision step). */
 int zsv_cl_bf16_to_ncs_f32(const void* x, int32_t N, int32_t S, int32_t C, float* out, void* stream);

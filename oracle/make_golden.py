@@ -463,6 +463,47 @@ def run_autocast_bf16():
     return out
 
 
+def run_autocast_bf16_c3d():
+    """The imported reference's C3D (network.py:95-180) under ``torch.autocast("cpu", dtype=torch.bfloat16)``, eval mode (its
+    dropout is RNG-dependent; C3D has no BatchNorm, so eval == train otherwise), one 16x112x112 clip: embedding, loss, and
+    per-parameter gradient norms / cosines against its own fp32 gradients -- the noise floor ``amp.Bf16TrainPathC3D`` is held to."""
+    ref_network, _ = import_reference()
+    opt = R.make_opt("c3d")
+    torch.manual_seed(0)
+    ref = ref_network.get_network(opt)
+    weights = S.keyed_state_dict(ref.state_dict(), seed=0, bn_jitter=False)
+    ref.load_state_dict(weights)
+    ref.eval()
+    x = S.synthetic_clips(1, 16, 112)
+    _, z = S.synthetic_targets(1)
+    out = {}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = R.embed(ref, x)
+        loss = F.mse_loss(y, z)
+    loss.backward()
+    out["emb"] = y.detach().float().numpy()
+    out["loss"] = np.float64(loss.item())
+    names = [k for k, p in ref.named_parameters() if p.grad is not None]
+    g16 = {k: dict(ref.named_parameters())[k].grad.detach().clone() for k in names}
+    ref.zero_grad()
+    y32 = R.embed(ref, x)
+    loss32 = F.mse_loss(y32, z)
+    loss32.backward()
+    g32 = {k: dict(ref.named_parameters())[k].grad.detach().clone() for k in names}
+    out["emb_f32"] = y32.detach().numpy()
+    out["loss_f32"] = np.float64(loss32.item())
+    out["grad_names"] = np.array(names)
+    out["grad_norm"] = np.array([g16[k].double().norm().item() for k in names])
+    out["grad_norm_f32"] = np.array([g32[k].double().norm().item() for k in names])
+    cos = []
+    for k in names:
+        a, b = g16[k].double().flatten(), g32[k].double().flatten()
+        cos.append(float(a @ b / (a.norm() * b.norm() + 1e-300)))
+    out["grad_cos_vs_f32"] = np.array(cos)
+    out["meta_n"], out["meta_frames"], out["meta_size"], out["meta_network"] = np.array(1), np.array(16), np.array(112), np.array("c3d")
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 8)
     ref_network, _ = import_reference()
@@ -470,7 +511,7 @@ def main():
     only = set(sys.argv[1:])
     for name, fn in (("transforms", run_transforms), ("transforms_t4", run_transforms_t4), ("accuracy", run_accuracy),
                      ("surface_extras", run_surface_extras), ("r2plus1d_t32_batch", run_t32_batch),
-                     ("r2plus1d_small_autocast_bf16", run_autocast_bf16)):
+                     ("r2plus1d_small_autocast_bf16", run_autocast_bf16), ("c3d_autocast_bf16", run_autocast_bf16_c3d)):
         if only and name not in only:
             continue
         t0 = time.time()

@@ -379,3 +379,83 @@ def test_autocast_surface():
         assert _cos(y_eval16[row], y_eval32[row]) >= 0.995
     with pytest.raises(RuntimeError):
         amp.trunk_features(model.model, x.reshape(2, 3, 8, 56, 56).cpu())
+
+
+@pytest.mark.parametrize("shape,kernel,pad", [((2, 64, 4, 12, 12), (1, 2, 2), (0, 0, 0)), ((1, 128, 4, 6, 6), (2, 2, 2), (0, 0, 0)),
+                                              ((3, 512, 2, 7, 7), (2, 2, 2), (0, 1, 1)), ((2, 64, 5, 7, 9), (2, 2, 2), (0, 0, 0))])
+def test_maxpool_backward_channels_last(shape, kernel, pad):
+    """zsv_maxpool3d_bf16_bwd against torch's MaxPool3d backward on the same bf16 values -- including ties (bf16 values repeat, and
+    post-ReLU windows are often all zero): the gradient goes to the FIRST maximum of a window, as aten's argmax does; voxels no
+    window covers (floor mode, last case) get zero."""
+    g = torch.Generator().manual_seed(sum(shape) + kernel[0])
+    x = torch.relu(torch.randn(shape, generator=g)).to(torch.bfloat16).float()           # many exact zeros and repeated values
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool3d(xr, kernel, kernel, pad)
+    dy = bf16_round(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    x_cl = to_cl(x)
+    dx_cl = amp.maxpool3d_bf16_bwd(to_cl(dy), x_cl, shape[1], kernel, pad)
+    torch.cuda.synchronize()
+    assert torch.equal(from_cl(dx_cl, shape[1]), xr.grad)
+    assert float(dx_cl[..., shape[1]:].float().abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 4, 9, 7), (1, 128, 2, 5, 5), (3, 512, 1, 4, 4)])
+def test_relu_bias_backward_channels_last(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.relu(bf16_round(torch.randn(shape, generator=g)))
+    dy = bf16_round(torch.randn(shape, generator=g))
+    gg, db = amp.relu_bias_bwd_cl(to_cl(dy), to_cl(y), shape[1])
+    torch.cuda.synchronize()
+    expect = dy * (y > 0)
+    assert torch.equal(from_cl(gg, shape[1]), expect)
+    ref = expect.double().sum(dim=(0, 2, 3, 4))
+    assert float((db.cpu().double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+
+
+def test_c3d_autocast_training_step_against_the_reference_under_cpu_autocast():
+    """network.C3D under amp.autocast() with gradients (amp.Bf16TrainPathC3D: eight relu(conv + bias) layers and five max-pools
+    forward and backward in bf16, the head in fp32) against the imported reference under torch.autocast("cpu", bfloat16)
+    (tests/golden/c3d_autocast_bf16.npz; eval mode: the dropout is RNG-dependent).  C3D has no BatchNorm, so bf16 is far less noisy
+    here than on the R(2+1)D trunk: the reference's own bf16 gradients have cosines of 0.937 ... 1.0 with its fp32 gradients."""
+    g = load_golden("c3d_autocast_bf16")
+    model = network.get_network(make_opt("c3d"))
+    weights = synthetic.keyed_state_dict(model.state_dict(), seed=0, bn_jitter=False)
+    model.load_state_dict(weights)
+    model.to(DEV).eval()
+    x = synthetic.synthetic_clips(1, 16, 112).to(DEV)
+    _, z = synthetic.synthetic_targets(1)
+    z = z.to(DEV)
+    model.zero_grad(set_to_none=True)
+    y32 = model(x)
+    F.mse_loss(y32, z).backward()
+    ops.join_wgrad_streams()
+    grads32 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    with amp.autocast():
+        y = model(x)
+        loss = F.mse_loss(y, z)
+    loss.backward()
+    ops.join_wgrad_streams()
+    torch.cuda.synchronize()
+    for name, ref in (("autocast oracle", g["emb"]), ("fp32 oracle", g["emb_f32"])):
+        ref = torch.from_numpy(np.asarray(ref, dtype=np.float32))
+        assert _cos(y[0].cpu(), ref[0]) >= 0.999, name
+        assert float((y.cpu() - ref).abs().max()) <= 1e-2, name
+    assert abs(loss.item() - float(g["loss"])) <= 0.02 * float(g["loss"])
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    names = [str(k) for k in g["grad_names"]]
+    assert sorted(grads) == sorted(names) == sorted(grads32)
+    for k, oc, n32 in zip(names, g["grad_cos_vs_f32"], g["grad_norm_f32"]):
+        assert grads[k].dtype == torch.float32 and torch.isfinite(grads[k]).all(), k
+        assert _cos(grads[k], grads32[k]) >= float(oc) - 0.05, (k, _cos(grads[k], grads32[k]), float(oc))
+        ratio = float(grads[k].double().norm()) / float(n32)
+        assert 0.85 <= ratio <= 1.15, (k, ratio)          # (the oracle's own bf16 / fp32 norm ratios: 0.984 ... 1.024; conv1.bias measured 1.11 here)
+    # a full step with the scaler runs and moves the loss
+    model.load_state_dict(weights)
+    opt = optim.FusedAdam(model.parameters(), lr=1e-4)
+    scaler = optim.LossScaler(init_scale=2.0 ** 12)
+    crit = torch.nn.MSELoss()
+    losses = [train.train_step(model, opt, crit, x, z, scaler=scaler, autocast=True)[1] for _ in range(6)]
+    torch.cuda.synchronize()
+    assert losses[-1].item() < losses[0].item()

@@ -90,6 +90,8 @@ SIGNATURES = {
     "zsv_bn_cl_bwd": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_bf16_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_bf16_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_maxpool3d_bf16_bwd": (c_int, [_P, _P] + [c_int32] * 14 + [_P, _P]),
+    "zsv_relu_bias_bwd_cl": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, c_size_t, _P]),
     "zsv_cl_bf16_to_ncs_f32": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_ncs_f32_to_cl_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_meanpool_bf16_bwd": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),

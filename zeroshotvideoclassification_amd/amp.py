@@ -147,6 +147,33 @@ def ncdhw_to_cl_bf16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def maxpool3d_bf16_bwd(dy: torch.Tensor, x: torch.Tensor, channels: int, kernel, padding) -> torch.Tensor:
+    """Gradient of ``inference.maxpool3d_bf16`` (nn.MaxPool3d with stride == kernel) on channels-last bf16."""
+    n, t, h, w, _ = x.shape
+    kt, kh, kw = (int(v) for v in kernel)
+    pt, ph, pw = (int(v) for v in padding)
+    to, ho, wo = dy.shape[1:4]
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().zsv_maxpool3d_bf16_bwd(dy.data_ptr(), x.data_ptr(), n, channels, t, h, w, kt, kh, kw, pt, ph, pw, to, ho, wo,
+                                                  dx.data_ptr(), ops._stream()), "zsv_maxpool3d_bf16_bwd")
+    return dx
+
+
+def relu_bias_bwd_cl(dy: torch.Tensor, y: torch.Tensor, channels: int, want_bias: bool = True):
+    """``relu(conv(x) + bias)`` backward on channels-last bf16: (dy * (y > 0), bias gradient (fp32) or None)."""
+    lib = _lib.load()
+    r = _rows(y)
+    nbytes = lib.zsv_bn_cl_workspace_bytes(r, channels)
+    if nbytes == 0:
+        raise RuntimeError(f"zsv_relu_bias_bwd_cl: unsupported shape rows={r} channels={channels}")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
+    g = torch.empty_like(y)
+    db = torch.empty(channels, dtype=torch.float32, device=y.device) if want_bias else None
+    _lib.check(lib.zsv_relu_bias_bwd_cl(dy.data_ptr(), y.data_ptr(), r, channels, g.data_ptr(), ops._ptr(db), ws.data_ptr(), nbytes,
+                                        ops._stream()), "zsv_relu_bias_bwd_cl")
+    return g, db
+
+
 def meanpool_bf16_bwd(dpooled: torch.Tensor, like: torch.Tensor, channels: int) -> torch.Tensor:
     n, t, h, w, _ = like.shape
     dx = torch.empty_like(like)
@@ -157,10 +184,11 @@ def meanpool_bf16_bwd(dpooled: torch.Tensor, like: torch.Tensor, channels: int) 
 
 # ---- one Conv3d -> BatchNorm3d (-> + residual) (-> ReLU) unit -----------------------------------------------------------
 class _Unit:
-    def __init__(self, conv: nn.Conv3d, bn: nn.BatchNorm3d, relu: bool):
-        if bn is None:
+    def __init__(self, conv: nn.Conv3d, bn: Optional[nn.BatchNorm3d], relu: bool, plain: bool = False):
+        """``plain``: C3D's ``relu(conv(x) + bias)`` (network.py:147-162): no BatchNorm, a bias."""
+        if bn is None and not plain:
             raise RuntimeError("amp: every trunk convolution is followed by a BatchNorm3d in the reference's VideoResNet")
-        if conv.bias is not None or tuple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
+        if (conv.bias is not None and not plain) or tuple(conv.dilation) != (1, 1, 1) or conv.groups != 1:
             raise RuntimeError("amp: bias / dilation / groups are not used by the reference's trunks and not supported")
         self.conv, self.bn, self.relu = conv, bn, relu
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
@@ -403,6 +431,126 @@ class Bf16TrainPath:
             dx, _, _ = unit_bwd(dx, need_dx=(i > 0))
         assert idx == -1
         return grads
+
+
+class Bf16TrainPathC3D:
+    """``network.C3D``'s eight ``relu(conv + bias)`` layers and five max-pools (network.py:147-163) forward and backward in bf16 on
+    the channels-last layout; fc6 / dropout / clip mean / regressor / normalisation stay fp32 in the module (autocast's output
+    of the last pool, flattened in the module's (C, T, H, W) order, is this path's result)."""
+
+    def __init__(self, model: nn.Module):
+        from .inference import Bf16EngineC3D
+        self.model = model
+        self.layers = []
+        for conv_name, pool_name in Bf16EngineC3D.LAYERS:
+            conv = getattr(model, conv_name)
+            u = _Unit(conv, None, True, plain=True)
+            pool = getattr(model, pool_name) if pool_name else None
+            if pool is not None:
+                k, st, pd = pool.kernel_size, pool.stride, pool.padding
+                k = (k,) * 3 if isinstance(k, int) else tuple(k)
+                st = k if st is None else ((st,) * 3 if isinstance(st, int) else tuple(st))
+                pd = (pd,) * 3 if isinstance(pd, int) else tuple(pd)
+                if st != k:
+                    raise RuntimeError("amp: max-pools with stride != kernel are not used by the reference")
+                pool = (k, pd)
+            self.layers.append((u, pool))
+        if not self.layers[0][0].folded:
+            raise RuntimeError("amp: C3D's conv1 must take the clip (<= 4 channels)")
+        self.features = self.layers[-1][0].cout
+        self.params = []
+        for u, _ in self.layers:
+            self.params += [u.conv.weight, u.conv.bias]
+
+    def forward(self, clips: torch.Tensor, tape):
+        first = self.layers[0][0]
+        n, _, t, h, w = clips.shape
+        kt, kh, kw = first.kernel
+        ph, pw = first.padding[1], first.padding[2]
+        wo = (w + 2 * pw - kw) // first.stride[2] + 1
+        hp, wp = h + 2 * ph, max(w + 2 * pw, (wo - 1) * first.stride[2] + 8)
+        x = clip_to_bf16(clips, ph, pw, hp, wp)
+        for i, (u, pool) in enumerate(self.layers):
+            nn_, t_, h_, w_, _ = x.shape
+            d = u.desc(nn_, t_, h_, w_, wo if i == 0 else None)
+            bias = u.conv.bias.detach() if u.conv.bias is not None else None
+            blob = pack_conv(d, u.conv.weight.detach(), None, bias)
+            y = conv_bf16(d, x, blob, None, True)                    # relu(conv(x) + bias), one rounding to bf16
+            r = _Record()
+            r.unit, r.x, r.z, r.y, r.mean, r.invstd, r.desc, r.has_res, r.clips, r.coef = u, x, None, y, None, None, d, False, \
+                (clips if i == 0 else None), None
+            x = y
+            pooled = None
+            if pool is not None:
+                pooled = maxpool3d_bf16_fwd(y, u.cout, pool[0], pool[1])
+                x = pooled
+            if tape is not None:
+                tape.append((r, pool, pooled))
+        return x
+
+    def backward(self, tape, dlast: torch.Tensor):
+        grads = {}
+        dx = dlast
+        for i in range(len(tape) - 1, -1, -1):
+            r, pool, pooled = tape[i]
+            u = r.unit
+            if pool is not None:
+                dx = maxpool3d_bf16_bwd(dx, r.y, u.cout, pool[0], pool[1])
+            need_bias = u.conv.bias is not None and u.conv.bias.requires_grad
+            g, db = relu_bias_bwd_cl(dx, r.y, u.cout, want_bias=need_bias)
+            if need_bias:
+                grads[id(u.conv.bias)] = db
+            if u.conv.weight.requires_grad:
+                grads[id(u.conv.weight)] = Bf16TrainPath._wgrad(r, g)
+            dx = Bf16TrainPath._dgrad(r, g) if i > 0 else None
+        return grads
+
+
+def maxpool3d_bf16_fwd(x, channels, kernel, padding):
+    from .inference import maxpool3d_bf16
+    return maxpool3d_bf16(x, channels, kernel, padding)
+
+
+class _C3DTrunkBf16(Function):
+    """(N, 8192) fp32 = C3D's last pooled feature map flattened in (C, T, H, W) order (network.py:165), computed in bf16; fp32
+    gradients for the convolution weights and biases, none for the clip."""
+
+    @staticmethod
+    def forward(ctx, clips, path, *params):
+        ops._require(clips)
+        tape = [] if any(p.requires_grad for p in params) else None
+        with torch.cuda.device(clips.device):
+            last = path.forward(clips.contiguous(), tape)
+            n = last.shape[0]
+            feat = last[..., :path.features].permute(0, 4, 1, 2, 3).reshape(n, -1).float()
+        ctx.path, ctx.tape, ctx.last_shape = path, tape, tuple(last.shape)
+        ctx.n_params = len(params)
+        ctx.set_materialize_grads(False)
+        return feat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dfeat):
+        path, tape = ctx.path, ctx.tape
+        if dfeat is None or tape is None:
+            return (None, None) + (None,) * ctx.n_params
+        n, t, h, w, _ = ctx.last_shape
+        with torch.cuda.device(dfeat.device):
+            dlast = ncdhw_to_cl_bf16(dfeat.float().reshape(n, path.features, t, h, w))
+            grads = path.backward(tape, dlast)
+        ctx.tape = None
+        out = [grads.get(id(p)) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(path.params)]
+        return (None, None) + tuple(out)
+
+
+def c3d_features(model: nn.Module, clips: torch.Tensor) -> torch.Tensor:
+    """``network.C3D.forward`` up to ``view(-1, 8192)`` (network.py:147-165) for (N, 3, 16, 112, 112) fp32 clips, in bf16."""
+    if not clips.is_cuda:
+        raise RuntimeError("amp: MI355X HIP tensors only (there is no CPU fallback)")
+    path = model.__dict__.get("_zsv_bf16_train_path")
+    if path is None:
+        path = model.__dict__["_zsv_bf16_train_path"] = Bf16TrainPathC3D(model)
+    return _C3DTrunkBf16.apply(clips, path, *path.params)
 
 
 def train_path_for(trunk: nn.Module) -> Bf16TrainPath:

@@ -319,6 +319,92 @@ __global__ void meanpool_cl_bwd_kernel(const float* __restrict__ dp, int S, int 
     dx[i] = c < C ? (unsigned short)to_bf16_bits(dp[n * C + c] / (float)S) : (unsigned short)0;
 }
 
+
+// ---- C3D's training step in bf16 (network.py:147-163 under autocast): max-pool backward and ReLU mask + bias gradient ---------
+// MaxPool3d (kernel == stride) backward on channels-last bf16: one thread per (window, 8-channel octet) finds the window's FIRST
+// maximum in (t, h, w) scan order per channel -- aten::max_pool3d_with_indices' argmax -- and writes dy there and zero to the
+// window's other voxels (a voxel belongs to exactly one window; voxels no window covers are zeroed by the caller).
+__global__ void maxpool3d_cl_bwd_kernel(const u32x4v* __restrict__ dy, const u32x4v* __restrict__ x, int Ti, int Hi, int Wi, int G, int kT,
+                                        int kH, int kW, int pT, int pH, int pW, int To, int Ho, int Wo, long total, u32x4v* __restrict__ dx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int o = (int)(idx % G);
+    long r = idx / G;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int to = (int)(r % To);
+    const long n = r / To;
+    float best[8], g[8];
+    int arg[8];
+    unpack8(dy[idx], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = -1; }
+    int tap = 0;
+    for (int a = 0; a < kT; ++a)
+        for (int b = 0; b < kH; ++b)
+            for (int c = 0; c < kW; ++c, ++tap) {
+                const int t = to * kT + a - pT, h = ho * kH + b - pH, w = wo * kW + c - pW;
+                if ((unsigned)t >= (unsigned)Ti || (unsigned)h >= (unsigned)Hi || (unsigned)w >= (unsigned)Wi) continue;
+                float v[8];
+                unpack8(x[(((n * Ti + t) * Hi + h) * (long)Wi + w) * G + o], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (v[j] > best[j] || arg[j] < 0) { best[j] = v[j]; arg[j] = tap; }
+            }
+    tap = 0;
+    for (int a = 0; a < kT; ++a)
+        for (int b = 0; b < kH; ++b)
+            for (int c = 0; c < kW; ++c, ++tap) {
+                const int t = to * kT + a - pT, h = ho * kH + b - pH, w = wo * kW + c - pW;
+                if ((unsigned)t >= (unsigned)Ti || (unsigned)h >= (unsigned)Hi || (unsigned)w >= (unsigned)Wi) continue;
+                float outv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) outv[j] = arg[j] == tap ? g[j] : 0.f;
+                dx[(((n * Ti + t) * Hi + h) * (long)Wi + w) * G + o] = pack8(outv);
+            }
+}
+
+// g = dy * (y > 0) (bf16) and the per-block partial sums of g per channel (the bias gradient): `relu(conv(x) + bias)` backward
+__global__ __launch_bounds__(256) void relu_bias_bwd_cl_kernel(ClShape sh, const u32x4v* __restrict__ dy, const u32x4v* __restrict__ y,
+                                                               u32x4v* __restrict__ gout, float* __restrict__ partial) {
+    extern __shared__ float red[];                 // [RL][2][Cp] (second half unused: the layout of partial_sums_16)
+    const int o = threadIdx.x % sh.G, rl = threadIdx.x / sh.G;
+    float s0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s0[j] = 0.f;
+    const long row0 = (long)blockIdx.x * sh.rows_per_block;
+    long row_end = row0 + sh.rows_per_block;
+    if (row_end > sh.R) row_end = sh.R;
+    if (rl < sh.RL) {
+        for (long r = row0 + rl; r < row_end; r += sh.RL) {
+            const long idx = r * sh.G + o;
+            float gv[8], yv[8];
+            unpack8(__builtin_nontemporal_load(dy + idx), gv);
+            unpack8(__builtin_nontemporal_load(y + idx), yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gv[j] = yv[j] > 0.f ? gv[j] : 0.f; s0[j] += gv[j]; }
+            gout[idx] = pack8(gv);
+        }
+        float* mine = red + (size_t)rl * 2 * sh.Cp + o * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mine[j] = s0[j]; mine[sh.Cp + j] = 0.f; }
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * 2 * sh.Cp;
+    for (int c = threadIdx.x; c < 2 * sh.Cp; c += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < sh.RL; ++l) acc += red[(size_t)l * 2 * sh.Cp + c];
+        out[c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ partial, int nb, int C, int Cp, float* __restrict__ dbias) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    double s, unused;
+    partial_sums_16(partial, nb, Cp, c, s, unused);
+    if ((threadIdx.x >> 4) == 0 && c < C) dbias[c] = (float)s;
+}
+
 static int cl_shape(long R, int C, ClShape* sh, int* nb) {
     if (R <= 0 || C <= 0) return ZSV_E_BAD_SHAPE;
     const int Cp = C <= 4 ? 4 : (C + 31) / 32 * 32;
@@ -406,6 +492,44 @@ int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32
     else if (mask == 2) { if (g_out) ZSV_BWD_APPLY(2, true); else ZSV_BWD_APPLY(2, false); }
     else { if (g_out) ZSV_BWD_APPLY(0, true); else ZSV_BWD_APPLY(0, false); }
 #undef ZSV_BWD_APPLY
+    return launch_status();
+}
+
+int zsv_maxpool3d_bf16_bwd(const void* dy, const void* x, int32_t N, int32_t C, int32_t Ti, int32_t Hi, int32_t Wi, int32_t kT, int32_t kH,
+                           int32_t kW, int32_t pT, int32_t pH, int32_t pW, int32_t To, int32_t Ho, int32_t Wo, void* dx, void* stream) {
+    if (N <= 0 || C <= 4 || Ti <= 0 || Hi <= 0 || Wi <= 0 || kT <= 0 || kH <= 0 || kW <= 0 || pT < 0 || pH < 0 || pW < 0)
+        return ZSV_E_BAD_SHAPE;
+    if (2 * pT > kT || 2 * pH > kH || 2 * pW > kW) return ZSV_E_BAD_SHAPE;
+    if (To != (Ti + 2 * pT - kT) / kT + 1 || Ho != (Hi + 2 * pH - kH) / kH + 1 || Wo != (Wi + 2 * pW - kW) / kW + 1 || To <= 0 ||
+        Ho <= 0 || Wo <= 0)
+        return ZSV_E_BAD_SHAPE;
+    if (!dy || !x || !dx) return ZSV_E_NULL;
+    const int G = (C + 31) / 32 * 32 / 8;
+    if ((long)N * Ti * Hi * Wi * G >= (1L << 31)) return ZSV_E_TOO_LARGE;
+    hipStream_t s = (hipStream_t)stream;
+    // voxels past the last window (floor mode) receive no gradient: zero the tensor first only then
+    if (To * kT - pT < Ti || Ho * kH - pH < Hi || Wo * kW - pW < Wi) {
+        if (hipMemsetAsync(dx, 0, (size_t)N * Ti * Hi * Wi * G * 16, s) != hipSuccess) return ZSV_E_LAUNCH;
+    }
+    const long total = (long)N * To * Ho * Wo * G;
+    hipLaunchKernelGGL(maxpool3d_cl_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u32x4v*)dy, (const u32x4v*)x, Ti,
+                       Hi, Wi, G, kT, kH, kW, pT, pH, pW, To, Ho, Wo, total, (u32x4v*)dx);
+    return launch_status();
+}
+
+int zsv_relu_bias_bwd_cl(const void* dy, const void* y, int64_t R, int32_t C, void* g_out, float* dbias, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    ClShape sh;
+    int nb = 0;
+    const int st = cl_shape(R, C, &sh, &nb);
+    if (st != ZSV_OK) return st;
+    if (!dy || !y || !g_out || !workspace) return ZSV_E_NULL;
+    if (workspace_bytes < cl_workspace_bytes(sh, nb)) return ZSV_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const size_t lds = (size_t)sh.RL * 2 * sh.Cp * sizeof(float);
+    hipLaunchKernelGGL(relu_bias_bwd_cl_kernel, dim3(nb), dim3(256), lds, s, sh, (const u32x4v*)dy, (const u32x4v*)y, (u32x4v*)g_out, partial);
+    if (dbias) hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, partial, nb, C, sh.Cp, dbias);
     return launch_status();
 }
 

@@ -164,9 +164,17 @@ class C3D(nn.Module):
     def forward(self, x):
         bs, nc, ch, t, h, w = x.shape
         from . import amp
-        if amp.is_autocast_enabled() and x.is_cuda and not self.training and not torch.is_grad_enabled():
-            from .inference import engine_for                  # main.py:172 `with autocast():` around an eval forward
-            return engine_for(self, torch.bfloat16)(x)
+        if amp.is_autocast_enabled() and x.is_cuda:            # main.py:172 `with autocast():`
+            if not torch.is_grad_enabled() and not self.training:
+                from .inference import engine_for
+                return engine_for(self, torch.bfloat16)(x)      # eval forward: the bf16 engine
+            if torch.is_grad_enabled():
+                # the mixed-precision step: convolutions + pools forward and backward in bf16 (amp.Bf16TrainPathC3D), the head in fp32
+                a = amp.c3d_features(self, x.reshape(bs * nc, ch, t, h, w))
+                a = self.fc6(a, relu=True)
+                a = self.dropout(a)
+                a = a.reshape(bs, nc, -1).mean(1).reshape(bs, -1)
+                return F.normalize(self.regressor(a), dim=-1)
         a = x.reshape(bs * nc, ch, t, h, w)
         a = self.pool1(self.conv1(a, relu=True))
         a = self.pool2(self.conv2(a, relu=True))
