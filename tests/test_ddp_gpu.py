@@ -86,6 +86,40 @@ def _worker(rank, world, port):
             assert torch.equal(lo, hi), k                                   # replicas stay bit-identical
         moved = (model.output2emb_proj.layers[1].weight.detach() - state0["output2emb_proj.layers.1.weight"]).abs().max().item()
         assert 1e-4 < moved < 1e-2 and scaler.state()["steps_done"] == 2
+        # the mixed-precision step (main.py:172 `with autocast():`) under the same gradient sync: the bf16 trunk hands autograd all
+        # its parameter gradients at once (one Function), in a different order than the fp32 path produced them -- the buckets do
+        # not care; the reduced gradients are the average of the ranks' local bf16-path gradients and the replicas stay identical
+        from zeroshotvideoclassification_amd import amp, ops
+        model.load_state_dict(state0)
+        model.zero_grad(set_to_none=True)
+        with amp.autocast():
+            loss = crit(train.embed(model, x), z)
+        loss.backward()
+        ops.join_wgrad_streams()
+        ref16 = {}
+        for k, p in live():
+            g = p.grad.detach().clone()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            ref16[k] = g * (1.0 / world)
+        assert set(ref16) == set(ref)
+        model.load_state_dict(state0)
+        train.train_step(model, opt, crit, x, z, sync, autocast=True)
+        torch.cuda.synchronize()
+        for k, p in live():
+            err = (p.grad - ref16[k]).abs().max().item()
+            assert err <= 1e-6 * (ref16[k].abs().max().item() + 1e-12), ("autocast", k, err)
+        model.load_state_dict(state0)
+        fused16 = optim.FusedAdam(model.parameters(), lr=1e-3, grad_buckets=sync)
+        scaler16 = optim.LossScaler(init_scale=1024.0)
+        for step in range(2):
+            train.train_step(model, fused16, crit, x, z, sync, scaler16, autocast=True)
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            lo, hi = p.detach().clone(), p.detach().clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            assert torch.equal(lo, hi), ("autocast", k)
+        assert scaler16.state()["steps_done"] == 2
         dist.barrier()
     finally:
         dist.destroy_process_group()
