@@ -379,6 +379,31 @@ def test_autocast_surface():
         assert _cos(y_eval16[row], y_eval32[row]) >= 0.995
     with pytest.raises(RuntimeError):
         amp.trunk_features(model.model, x.reshape(2, 3, 8, 56, 56).cpu())
+    # training mode without gradients (torch.no_grad(), or a frozen trunk): the bf16 training forward runs, no tape is kept
+    model.train()
+    path = amp.train_path_for(model.model)
+    seen = {}
+    orig = path.forward
+    path.forward = lambda clips, tape: (seen.__setitem__("tape", tape), orig(clips, tape))[1]
+    try:
+        with torch.no_grad(), amp.autocast():
+            y_ng, _ = model(x)
+        assert seen["tape"] is None and not y_ng.requires_grad
+        for p in model.model.parameters():
+            p.requires_grad_(False)
+        with amp.autocast():
+            y_frozen, _ = model(x)
+        assert seen["tape"] is None
+        F.mse_loss(y_frozen, torch.zeros_like(y_frozen)).backward()       # the head still trains
+        assert model.output2emb_proj.layers[0].weight.grad is not None
+        assert all(p.grad is None for p in model.model.parameters())
+        for p in model.model.parameters():
+            p.requires_grad_(True)
+        with amp.autocast():
+            model(x)
+        assert isinstance(seen["tape"], list) and len(seen["tape"]) == len(path.units)
+    finally:
+        path.forward = orig
 
 
 @pytest.mark.parametrize("shape,kernel,pad", [((2, 64, 4, 12, 12), (1, 2, 2), (0, 0, 0)), ((1, 128, 4, 6, 6), (2, 2, 2), (0, 0, 0)),

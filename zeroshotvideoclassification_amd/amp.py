@@ -516,9 +516,9 @@ class _C3DTrunkBf16(Function):
     gradients for the convolution weights and biases, none for the clip."""
 
     @staticmethod
-    def forward(ctx, clips, path, *params):
+    def forward(ctx, clips, path, record, *params):
         ops._require(clips)
-        tape = [] if any(p.requires_grad for p in params) else None
+        tape = [] if record and any(p.requires_grad for p in params) else None
         with torch.cuda.device(clips.device):
             last = path.forward(clips.contiguous(), tape)
             n = last.shape[0]
@@ -533,14 +533,14 @@ class _C3DTrunkBf16(Function):
     def backward(ctx, dfeat):
         path, tape = ctx.path, ctx.tape
         if dfeat is None or tape is None:
-            return (None, None) + (None,) * ctx.n_params
+            return (None, None, None) + (None,) * ctx.n_params
         n, t, h, w, _ = ctx.last_shape
         with torch.cuda.device(dfeat.device):
             dlast = ncdhw_to_cl_bf16(dfeat.float().reshape(n, path.features, t, h, w))
             grads = path.backward(tape, dlast)
         ctx.tape = None
-        out = [grads.get(id(p)) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(path.params)]
-        return (None, None) + tuple(out)
+        out = [grads.get(id(p)) if ctx.needs_input_grad[3 + i] else None for i, p in enumerate(path.params)]
+        return (None, None, None) + tuple(out)
 
 
 def c3d_features(model: nn.Module, clips: torch.Tensor) -> torch.Tensor:
@@ -550,7 +550,7 @@ def c3d_features(model: nn.Module, clips: torch.Tensor) -> torch.Tensor:
     path = model.__dict__.get("_zsv_bf16_train_path")
     if path is None:
         path = model.__dict__["_zsv_bf16_train_path"] = Bf16TrainPathC3D(model)
-    return _C3DTrunkBf16.apply(clips, path, *path.params)
+    return _C3DTrunkBf16.apply(clips, path, torch.is_grad_enabled(), *path.params)
 
 
 def train_path_for(trunk: nn.Module) -> Bf16TrainPath:
@@ -565,9 +565,10 @@ class _TrunkBf16(Function):
     not produced (the clip is data), gradients for every trunk parameter are fp32."""
 
     @staticmethod
-    def forward(ctx, clips, path, *params):
+    def forward(ctx, clips, path, record, *params):
         ops._require(clips)
-        tape = [] if any(p.requires_grad for p in params) else None
+        # (`record`: grad mode at the call site -- inside a Function's forward it is always off; no tape under torch.no_grad())
+        tape = [] if record and any(p.requires_grad for p in params) else None
         with torch.cuda.device(clips.device):
             _state.nbt_pending = []
             try:
@@ -587,16 +588,16 @@ class _TrunkBf16(Function):
     def backward(ctx, dpooled):
         path, tape = ctx.path, ctx.tape
         if dpooled is None or tape is None:
-            return (None, None) + (None,) * ctx.n_params
+            return (None, None, None) + (None,) * ctx.n_params
         with torch.cuda.device(dpooled.device):
             dfeat = meanpool_bf16_bwd(dpooled.float(), ctx.feat_like, path.features)
             grads = path.backward(tape, dfeat)
         ctx.tape = None
         out = []
         for i, p in enumerate(path.params):
-            g = grads.get(id(p)) if ctx.needs_input_grad[2 + i] else None
+            g = grads.get(id(p)) if ctx.needs_input_grad[3 + i] else None
             out.append(g)
-        return (None, None) + tuple(out)
+        return (None, None, None) + tuple(out)
 
 
 def trunk_features(trunk: nn.Module, clips: torch.Tensor) -> torch.Tensor:
@@ -605,4 +606,4 @@ def trunk_features(trunk: nn.Module, clips: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("amp: MI355X HIP tensors only (there is no CPU fallback)")
     path = train_path_for(trunk)
     _lib.note_raw_write(parameters=False)               # BatchNorm running statistics are written through raw pointers
-    return _TrunkBf16.apply(clips, path, *path.params)
+    return _TrunkBf16.apply(clips, path, torch.is_grad_enabled(), *path.params)
