@@ -99,14 +99,19 @@ __device__ __forceinline__ void add_bf16x8(f32x4& lo, f32x4& hi, u32x4 r) {
 // A(i); reads return in issue order, so before using A(i) at most min(2, TM-1-i) younger reads may
 // still be out.  MASKED: column block j is zeroed unless keep_j != 0 (a tap outside the input).
 template <int TM, int TN, bool MASKED>
-__device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, unsigned sb, unsigned keep0, unsigned keep1,
-                                          unsigned keep2, unsigned keep3) {
-    static_assert(TN == 4, "fragment schedule is written for 4 column blocks");
+__device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, unsigned sb, const unsigned (&keep)[TN]) {
+    static_assert(TN == 4 || TN == 8, "fragment schedule is written for 4 or 8 column blocks");
     bf16x8 bf[TN], af[3];
     lds_read128<0>(bf[0], sb);
     lds_read128<1024>(bf[1], sb);
     lds_read128<2048>(bf[2], sb);
     lds_read128<3072>(bf[3], sb);
+    if constexpr (TN == 8) {
+        lds_read128<4096>(bf[4], sb);
+        lds_read128<5120>(bf[5], sb);
+        lds_read128<6144>(bf[6], sb);
+        lds_read128<7168>(bf[7], sb);
+    }
     lds_read128<0>(af[0], sa);
     if (TM > 1) lds_read128<1024>(af[1], sa);
 #pragma unroll
@@ -116,12 +121,12 @@ __device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, uns
             if (TM > 2) lds_wait<2>(af[0], bf[0], bf[1], bf[2], bf[3]);
             else if (TM > 1) lds_wait<1>(af[0], bf[0], bf[1], bf[2], bf[3]);
             else lds_wait<0>(af[0], bf[0], bf[1], bf[2], bf[3]);
+            if constexpr (TN == 8)       // (issued before af[0]: returned by the wait above; tie the registers to it)
+                asm volatile("" : "+v"(bf[4]), "+v"(bf[5]), "+v"(bf[6]), "+v"(bf[7]));
             if (MASKED) {
                 const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                bf[0] = keep0 ? bf[0] : z;
-                bf[1] = keep1 ? bf[1] : z;
-                bf[2] = keep2 ? bf[2] : z;
-                bf[3] = keep3 ? bf[3] : z;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = keep[j] ? bf[j] : z;
             }
         } else if (i + 2 < TM) lds_wait<2>(af[i % 3]);
         else if (i + 1 < TM) lds_wait<1>(af[i % 3]);
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
     for (int q = 0; q < prm.nq; ++q) {
         const bool ahead = q + 2 < prm.nq;
         if (ahead) issue(nxt2);
-        mfma_step<TM, TN, false>(acc, lds_base + cur * STAGE + a_frag, lds_base + cur * STAGE + b_frag, 0u, 0u, 0u, 0u);
+        const unsigned no_mask[TN] = {};
+        mfma_step<TM, TN, false>(acc, lds_base + cur * STAGE + a_frag, lds_base + cur * STAGE + b_frag, no_mask);
         // stage q+1 must have landed (all but this wave's newest NPW DMAs), for every wave
         if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,8 +505,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
             if (more_a) issue_a(abuf2);              // A first: the image issued after it may stay in flight
             if (more_b) issue_b((img + 1) & 1);
             const int tp = tap + c;
-            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag[c] + img_off, (mask[0] >> tp) & 1u,
-                                    (mask[1] >> tp) & 1u, (mask[2] >> tp) & 1u, (mask[3] >> tp) & 1u);
+            unsigned keepv[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keepv[j] = (mask[j] >> tp) & 1u;
+            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag[c] + img_off, keepv);
             // A(step+1) -- and before an image's first step the image -- must have landed, for every wave
             if (c < KW - 1 && more_a && img + 1 < nimg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW + NIW) : "memory");
             else if (c == KW - 1 && more_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
@@ -639,8 +647,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_tsame_kernel(Bf16Params prm,
             const bool more_b = c == 0 && img + 1 < nimg;
             if (more_a) issue_a(abuf2);
             if (more_b) issue_b((img + 1) & 1);
-            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag + img_off + c * HB * 64, (keep[0] >> c) & 1u,
-                                    (keep[1] >> c) & 1u, (keep[2] >> c) & 1u, (keep[3] >> c) & 1u);
+            unsigned keepv[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keepv[j] = (keep[j] >> c) & 1u;
+            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag + img_off + c * HB * 64, keepv);
             if (c < KT - 1 && more_a && img + 1 < nimg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW + NIW) : "memory");
             else if (c == KT - 1 && more_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -958,6 +968,9 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     }
     // 64 produced channels with many voxels: the input gradient of layer1's spatial convolutions in the bf16 training step
     // (144 -> 64 channels, K = 9 x 160; amp.py) -- the per-tap kernel gathers every input row nine times for 64 rows of MFMAs
+    // (a 64 x 512 tile -- eight column blocks per wave, half the LDS-DMA bytes per MFMA -- was built for this case and measured
+    // SLOWER: 0.538 vs 0.458 ms on layer1's input gradient, step 21.4 vs 21.1 ms on one device; the 80 KB of LDS per workgroup and
+    // the 33-piece image fill cost more than the bytes saved.  mfma_step keeps its 8-block form.)
     if (bf16_same_applicable(d) && bm == 64 && p.P >= 256 * 512 && ZSV_KNOB(BF16_NO_SAME64) == nullptr)
         return bf16_same_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
