@@ -89,7 +89,9 @@ def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torc
     invstd = torch.empty(c, dtype=torch.float32, device=z.device)
     coef = torch.empty((2, z.shape[-1]), dtype=torch.float32, device=z.device) if want_coef else None
     track = bn.track_running_stats and bn.running_mean is not None
-    momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+    if bn.momentum is None and track:
+        raise NotImplementedError("amp: BatchNorm3d(momentum=None) (cumulative moving average) is not used by the reference")
+    momentum = 0.0 if bn.momentum is None else float(bn.momentum)
     _lib.check(lib.zsv_bn_cl_fwd_train(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
                                        bn.running_mean.data_ptr() if track else None,
                                        bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
