@@ -25,6 +25,7 @@
 // alternate bank halves by row parity and differ in bit 1 / bit 3 of the row otherwise).
 // Bound: L2 -> LDS operand traffic and LDS read bandwidth (24 transposed reads per 27 MFMAs), not the matrix pipe.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "conv_params.h"
 #include "zsv_common.h"
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, con
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block -> (slice, image group, P panel, Q group): blocks of one voxel slice are neighbours (they share the operands in L2)
-    int b = blockIdx.x;
+    // block -> (slice, image group, P panel, Q group): the blocks of one voxel slice read the same operand rows; consecutive logical
+    // ids share an XCD (one L2) -- hardware deals consecutive blockIdx round-robin over the eight XCDs
+    int b = xcd_tile(gridDim.x, blockIdx.x);
     const int qg = b % prm.qgroups; b /= prm.qgroups;
     const int pp = b % prm.ppanels; b /= prm.ppanels;
     const int ig = b % prm.imggroups;
@@ -353,7 +355,9 @@ static WgradClPlan wgrad_cl_plan(const zsv_conv_desc* d) {
     pl.Qpad = pl.qgroups * pl.qb * 16;
     pl.chunks = (int)((P + 31) / 32);
     const int base = pl.ppanels * pl.qgroups * pl.imggroups;
-    int slices = (768 + base - 1) / base;
+    const char* e = ZSV_KNOB(BF16_WGRAD_WGS);
+    const int target = e ? atoi(e) : 384;          // workgroups per launch (measured 256 / 384 / 512 / 768: 384 gave the best step); every slice costs a partial-sum round trip
+    int slices = (target + base - 1) / base;
     if (slices > pl.chunks) slices = pl.chunks;
     if (slices < 1) slices = 1;
     pl.chunks_per_slice = (pl.chunks + slices - 1) / slices;
