@@ -196,6 +196,10 @@ def test_weight_gradient_of_bf16_operands(geom):
     ((1, 64, 4, 10, 10), 64, (3, 3, 3)),        # R3D-18
     ((2, 128, 2, 6, 6), 256, (3, 3, 3)),
     ((1, 64, 3, 5, 9), 64, (3, 1, 3)),          # odd extents, voxel count not a multiple of 32
+    ((2, 32, 2, 6, 6), 45, (1, 3, 3)),          # half an input panel, an output channel count that is no multiple of 16
+    ((2, 48, 3, 5, 5), 20, (3, 3, 3)),          # 75 voxels per clip: partial last chunk; 20 output channels (pitch 32)
+    ((1, 200, 4, 6, 6), 72, (3, 1, 1)),         # temporal form: 72 output channels (one panel and a bit), 200 input channels
+    ((5, 64, 1, 3, 3), 64, (1, 3, 3)),          # 45 voxels, W = 3: every voxel is on a border
 ])
 def test_native_bf16_weight_gradient_kernel(geom, monkeypatch):
     """zsv_conv3d_bf16_wgrad (csrc/wgrad_bf16.hip: voxel contraction through transposed LDS reads) against torch CPU fp64 on the
