@@ -200,20 +200,29 @@ def test_weight_gradient_of_bf16_operands(geom):
     ((2, 48, 3, 5, 5), 20, (3, 3, 3)),          # 75 voxels per clip: partial last chunk; 20 output channels (pitch 32)
     ((1, 200, 4, 6, 6), 72, (3, 1, 1)),         # temporal form: 72 output channels (one panel and a bit), 200 input channels
     ((5, 64, 1, 3, 3), 64, (1, 3, 3)),          # 45 voxels, W = 3: every voxel is on a border
+    # the gather form (one image per tap, rows fetched at strided input coordinates): the strided convolutions and the 1x1x1 shortcuts
+    ((2, 64, 4, 12, 12), 230, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ((2, 230, 4, 6, 6), 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),
+    ((2, 64, 4, 12, 12), 128, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+    ((1, 64, 4, 10, 10), 128, (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ((1, 128, 3, 7, 9), 96, (1, 3, 3), (1, 2, 2), (0, 1, 1)),      # odd extents
+    ((3, 256, 4, 14, 14), 921, (1, 3, 3), (1, 2, 2), (0, 1, 1)),   # S8-like: 4 input panels, 20 output-channel groups
+    ((2, 96, 2, 5, 5), 40, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # 1x1x1 stride 1
 ])
 def test_native_bf16_weight_gradient_kernel(geom, monkeypatch):
     """zsv_conv3d_bf16_wgrad (csrc/wgrad_bf16.hip: voxel contraction through transposed LDS reads) against torch CPU fp64 on the
     bf16-rounded operands (1e-3 of the gradient's range: fp32 accumulation), and against the converted-operand fp32 path."""
     from ctypes import byref
     from zeroshotvideoclassification_amd import _lib
-    xs, cout, k = geom
+    xs, cout, k = geom[:3]
     n, cin, t, h, w = xs
-    pad = tuple((v - 1) // 2 for v in k)
+    stride = geom[3] if len(geom) > 3 else (1, 1, 1)
+    pad = geom[4] if len(geom) > 4 else tuple((v - 1) // 2 for v in k)
     g = torch.Generator().manual_seed(cout * 5 + cin + t)
     x = bf16_round(torch.randn(xs, generator=g))
-    conv = torch.nn.Conv3d(cin, cout, k, padding=pad, bias=False)
+    conv = torch.nn.Conv3d(cin, cout, k, stride=stride, padding=pad, bias=False)
     w64 = conv.weight.detach().double().requires_grad_(True)
-    y64 = F.conv3d(x.double(), w64, None, 1, pad)
+    y64 = F.conv3d(x.double(), w64, None, stride, pad)
     dz = bf16_round(torch.randn(y64.shape, generator=g))
     y64.backward(dz.double())
     u = amp._Unit(conv.to(DEV), torch.nn.BatchNorm3d(cout).to(DEV), False)

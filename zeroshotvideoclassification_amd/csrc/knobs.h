@@ -15,6 +15,7 @@
     X(WINOT_NO_T32) \
     X(BF16_GROUP_OUTER) \
     X(BF16_NO_WGRAD) \
+    X(BF16_NO_WGRAD_GATHER) \
     X(BF16_WGRAD_WGS) \
     X(NO_DGRAD_S2) \
     X(NO_DGRAD_S2T) \

@@ -39,16 +39,18 @@ typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* wlds_ptr_t;
 
-__device__ wu32x4 zsv_wgrad_zero_line[8];      // 128 zero bytes: a padding row
-
 struct WgradClParams {
-    int P;                      // voxels N*T*H*W
-    int T, H, W;
+    int P;                      // rows of the Q operand = voxels the contraction runs over (N*To*Ho*Wo; stride 1: = input voxels)
+    int T, H, W;                // extents those voxels are decoded in (the OUTPUT's; stride 1: = the input's)
     Magic mW, mH, mT;
     int ppitch, qpitch;         // channel pitches of the P / Q tensors (elements)
+    unsigned p_bytes, q_bytes;  // sizes of the two tensors (buffer descriptors: a row outside reads as zeros)
     int pW;                     // (KW - 1) / 2
     int sgn;                    // +1: P = x read at v + shift; -1: P = dz read at v - shift
     int kH, pT, pH;             // row tap r = a * kH + b -> (a - pT, b - pH)
+    // GATHER form (strided convolutions, 1x1x1): P = x, one image per TAP, read at (to*sT + a - pT, ho*sH + b - pH, wo*sW + c - pW)
+    int kW3, sT, sH, sW, pWg;   // kernel width (tap -> (a, b, c)), strides, w padding
+    int Ti, Hi, Wi;             // input extents
     int qgroups, ppanels, imggroups;
     int taps;                   // kT * kH * kW
     int chunks, chunks_per_slice;
@@ -64,10 +66,12 @@ __device__ __forceinline__ wu32x2 tr_read(unsigned addr) {
 }
 __device__ __forceinline__ void tie(wu32x2& v) { asm volatile("" : "+v"(v)); }
 
-template <int NIMG, int KW, int QB>
+// GATHER: one image per tap, rows fetched at strided input coordinates (KW = 1; no flattened shifts, no border masks)
+template <int NIMG, int KW, int QB, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, const __bf16* __restrict__ Pt,
                                                           const __bf16* __restrict__ Qt, float* __restrict__ part) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!GATHER || KW == 1, "the gather form stages one image per tap");
     constexpr int TAPS = NIMG * KW;
     constexpr int PR8 = (32 + KW - 1 + 7) / 8;            // 1-KiB pieces (8 rows) per P image: 5 (KW = 3) or 4
     constexpr int QPAN = (QB * 16 + 63) / 64;             // Q panels of 64 channels
@@ -88,19 +92,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, con
     int c_end = c_begin + prm.chunks_per_slice;
     if (c_end > prm.chunks) c_end = prm.chunks;
 
-    // ---- DMA side: this lane's (row in piece, slot) -------------------------------------------------------------------------
+    // ---- DMA side: this lane's (row in piece, slot).  Rows come through buffer descriptors: one 32-bit byte offset per lane, a row
+    // outside the clip (or a channel past the pitch) gets an offset past the descriptor's range and reads as zeros -- no pointer
+    // selects, no zero line.
     const int drow = lane >> 3, dpos = lane & 7;
-    const __bf16* zero = (const __bf16*)zsv_wgrad_zero_line;
-    int da[NIMG], db[NIMG], dshift[NIMG];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Pt), 0, prm.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Qt), 0, prm.q_bytes, 0x00020000);
+    int da[NIMG], db[NIMG], dc[NIMG], dshift[NIMG];
 #pragma unroll
     for (int i = 0; i < NIMG; ++i) {
         const int rt = ig * NIMG + i;
-        const int a = rt / prm.kH, bb = rt - a * prm.kH;
-        da[i] = prm.sgn * (a - prm.pT);
-        db[i] = prm.sgn * (bb - prm.pH);
-        dshift[i] = (da[i] * prm.H + db[i]) * prm.W;
+        if (GATHER) {
+            const int c = rt % prm.kW3, ab = rt / prm.kW3;
+            const int a = ab / prm.kH, bb = ab - a * prm.kH;
+            da[i] = a - prm.pT; db[i] = bb - prm.pH; dc[i] = c - prm.pWg;
+            dshift[i] = 0;
+        } else {
+            const int a = rt / prm.kH, bb = rt - a * prm.kH;
+            da[i] = prm.sgn * (a - prm.pT);
+            db[i] = prm.sgn * (bb - prm.pH);
+            dc[i] = 0;
+            dshift[i] = 2 * prm.ppitch * ((da[i] * prm.H + db[i]) * prm.W);      // bytes
+        }
     }
     const int p_ch0 = pp * 64, q_ch0 = qg * QB * 16;
+    const int p_row_bytes = 2 * prm.ppitch, q_row_bytes = 2 * prm.qpitch;
 
     auto issue = [&](int chunk, int stage) {
         const int v0 = chunk * 32;
@@ -113,33 +130,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_cl_kernel(WgradClParams prm, con
                 const int u = v0 + r - prm.pW;
                 const int slot = dpos ^ (row_sz(r) << 1);
                 const int ch = p_ch0 + 8 * slot;
-                int t = 0, h = 0;
                 const bool inside = (unsigned)u < (unsigned)prm.P && ch < prm.ppitch;
-                if (inside) {
-                    const unsigned q1 = mdiv((unsigned)u, prm.mW);
-                    const unsigned q2 = mdiv(q1, prm.mH);
-                    const unsigned q3 = mdiv(q2, prm.mT);
-                    h = (int)(q1 - q2 * prm.H);
-                    t = (int)(q2 - q3 * prm.T);
-                }
+                const unsigned uu = inside ? (unsigned)u : 0u;
+                const unsigned q1 = mdiv(uu, prm.mW);
+                const unsigned q2 = mdiv(q1, prm.mH);
+                const unsigned q3 = mdiv(q2, prm.mT);
+                const int w = (int)(uu - q1 * prm.W), h = (int)(q1 - q2 * prm.H), t = (int)(q2 - q3 * prm.T);
+                if (GATHER) {
+                    const int ti0 = t * prm.sT, hi0 = h * prm.sH, wi0 = w * prm.sW;
+                    const int nbase = (int)q3 * prm.Ti;
 #pragma unroll
-                for (int i = 0; i < NIMG; ++i) {
-                    const bool ok = inside && (unsigned)(t + da[i]) < (unsigned)prm.T && (unsigned)(h + db[i]) < (unsigned)prm.H;
-                    const __bf16* src = ok ? Pt + ((size_t)(u + dshift[i]) * prm.ppitch + ch) : zero + 8 * (dpos & 7);
-                    __builtin_amdgcn_global_load_lds(src, (wlds_ptr_t)(base + (i * PR8 + rp) * 1024), 16, 0, 0);
+                    for (int i = 0; i < NIMG; ++i) {
+                        const int ti = ti0 + da[i], hi = hi0 + db[i], wi = wi0 + dc[i];
+                        const bool ok = inside && (unsigned)ti < (unsigned)prm.Ti && (unsigned)hi < (unsigned)prm.Hi && (unsigned)wi < (unsigned)prm.Wi;
+                        const unsigned off = (unsigned)(((nbase + ti) * prm.Hi + hi) * prm.Wi + wi) * (unsigned)p_row_bytes + 2u * (unsigned)ch;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (wlds_ptr_t)(base + (i * PR8 + rp) * 1024), 16, (int)(ok ? off : OOB), 0, 0, 0);
+                    }
+                } else {
+                    const unsigned off0 = uu * (unsigned)p_row_bytes + 2u * (unsigned)ch;
+#pragma unroll
+                    for (int i = 0; i < NIMG; ++i) {
+                        const bool ok = inside && (unsigned)(t + da[i]) < (unsigned)prm.T && (unsigned)(h + db[i]) < (unsigned)prm.H;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (wlds_ptr_t)(base + (i * PR8 + rp) * 1024), 16,
+                                                                 (int)(ok ? off0 + (unsigned)dshift[i] : OOB), 0, 0, 0);
+                    }
                 }
             }
         }
         {
             const int r = 8 * wave + drow;
-            const int u = v0 + r;
             const int slot = dpos ^ (row_sz(r) << 1);
+            // (a row past the last voxel lies past the descriptor's range by itself; a channel past the pitch must be sent there)
+            const unsigned off0 = (unsigned)(v0 + r) * (unsigned)q_row_bytes + 2u * (unsigned)(q_ch0 + 8 * slot);
 #pragma unroll
             for (int pn = 0; pn < QPAN; ++pn) {
-                const int ch = q_ch0 + pn * 64 + 8 * slot;
-                const bool ok = u < prm.P && ch < prm.qpitch;
-                const __bf16* src = ok ? Qt + ((size_t)u * prm.qpitch + ch) : zero + 8 * (dpos & 7);
-                __builtin_amdgcn_global_load_lds(src, (wlds_ptr_t)(base + P_BYTES + (pn * 4 + wave) * 1024), 16, 0, 0);
+                const bool ok = q_ch0 + pn * 64 + 8 * slot < prm.qpitch && v0 + r < prm.P;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (wlds_ptr_t)(base + P_BYTES + (pn * 4 + wave) * 1024), 16,
+                                                         (int)(ok ? off0 + 128u * (unsigned)pn : OOB), 0, 0, 0);
             }
         }
     };
@@ -319,8 +346,12 @@ __global__ __launch_bounds__(256) void wgrad_cl_reduce_kernel(const float* __res
 
 struct WgradClPlan {
     bool ok;
-    int mode;                  // 0: kW = 3, P = x, Q = dz, QB = 3;  1: 3x1x1, P = dz, Q = x, QB = 9
+    // 0: stride 1 "same", kW = 3: P = x, Q = dz, QB = 3 (three kw taps per row-tap image);  1: stride 1 "same" 3x1x1: P = dz, Q = x, QB = 9
+    // gather forms (strided convolutions, 1x1x1; one image per tap, P = x, Q = dz):  2: kH = kW = 3 (9 taps per workgroup, QB = 3);
+    // 3: 3x1x1 (QB = 9);  4: 1x1x1 (QB = 9)
+    int mode;
     int qb, qgroups, ppanels, imggroups, taps, chunks, chunks_per_slice, slices, Ptot, Qpad, Pch, Qch, ppitch, qpitch;
+    long rows;                 // voxels of the contraction
 };
 
 static inline int rup(int a, int b) { return (a + b - 1) / b * b; }
@@ -330,30 +361,42 @@ static WgradClPlan wgrad_cl_plan(const zsv_conv_desc* d) {
     pl.ok = false;
     if (d == nullptr || conv_check(d) != ZSV_OK) return pl;
     if (ZSV_KNOB(BF16_NO_WGRAD) != nullptr) return pl;
-    if (d->Cin <= 4 || d->sT != 1 || d->sH != 1 || d->sW != 1) return pl;
-    if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi) return pl;
-    if (2 * d->pT != d->kT - 1 || 2 * d->pH != d->kH - 1 || 2 * d->pW != d->kW - 1) return pl;
-    const long P = (long)d->N * d->Ti * d->Hi * d->Wi;
-    if (P >= (1L << 30)) return pl;
+    if (d->Cin <= 4) return pl;
     const int cinp = rup(d->Cin, 32), coutp = rup(d->Cout, 32);
-    if (d->kW == 3 && (d->kT * d->kH == 3 || d->kT * d->kH == 9) && (d->kH == 3 || d->kH == 1) && (d->kT == 3 || d->kT == 1)) {
+    const long in_vox = (long)d->N * d->Ti * d->Hi * d->Wi, out_vox = (long)d->N * d->To * d->Ho * d->Wo;
+    // 32-bit byte offsets inside the two buffer descriptors
+    if (in_vox * cinp * 2 >= (1L << 32) - 64 || out_vox * coutp * 2 >= (1L << 32) - 64 || out_vox >= (1L << 30)) return pl;
+    const bool same = d->sT == 1 && d->sH == 1 && d->sW == 1 && d->To == d->Ti && d->Ho == d->Hi && d->Wo == d->Wi &&
+                      2 * d->pT == d->kT - 1 && 2 * d->pH == d->kH - 1 && 2 * d->pW == d->kW - 1;
+    const int rowtaps = d->kT * d->kH;
+    pl.Pch = d->Cin; pl.Qch = d->Cout; pl.ppitch = cinp; pl.qpitch = coutp;
+    pl.imggroups = 1;
+    if (same && d->kW == 3 && (rowtaps == 3 || rowtaps == 9) && (d->kH == 3 || d->kH == 1) && (d->kT == 3 || d->kT == 1)) {
         pl.mode = 0; pl.qb = 3;
-        pl.Pch = d->Cin; pl.Qch = d->Cout; pl.ppitch = cinp; pl.qpitch = coutp;
-        pl.imggroups = d->kT * d->kH / 3;
-    } else if (d->kW == 1 && d->kH == 1 && d->kT == 3) {
+        pl.imggroups = rowtaps / 3;
+    } else if (same && d->kW == 1 && d->kH == 1 && d->kT == 3) {
         pl.mode = 1; pl.qb = 9;
         pl.Pch = d->Cout; pl.Qch = d->Cin; pl.ppitch = coutp; pl.qpitch = cinp;
-        pl.imggroups = 1;
+    } else if (ZSV_KNOB(BF16_NO_WGRAD_GATHER) != nullptr) {
+        return pl;
+    } else if (d->kH == 3 && d->kW == 3 && (d->kT == 1 || d->kT == 3)) {
+        pl.mode = 2; pl.qb = 3;
+        pl.imggroups = d->kT;
+    } else if (d->kT == 3 && d->kH == 1 && d->kW == 1) {
+        pl.mode = 3; pl.qb = 9;
+    } else if (d->kT == 1 && d->kH == 1 && d->kW == 1) {
+        pl.mode = 4; pl.qb = 9;
     } else {
         return pl;
     }
+    pl.rows = out_vox;
     pl.taps = d->kT * d->kH * d->kW;
     pl.ppanels = (pl.Pch + 63) / 64;
     pl.Ptot = pl.ppanels * 64;
     const int qblocks = (pl.Qch + 15) / 16;
     pl.qgroups = (qblocks + pl.qb - 1) / pl.qb;
     pl.Qpad = pl.qgroups * pl.qb * 16;
-    pl.chunks = (int)((P + 31) / 32);
+    pl.chunks = (int)((out_vox + 31) / 32);
     const int base = pl.ppanels * pl.qgroups * pl.imggroups;
     const char* e = ZSV_KNOB(BF16_WGRAD_WGS);
     const int target = e ? atoi(e) : 384;          // workgroups per launch (measured 256 / 384 / 512 / 768: 384 gave the best step); every slice costs a partial-sum round trip
@@ -366,14 +409,14 @@ static WgradClPlan wgrad_cl_plan(const zsv_conv_desc* d) {
     return pl;
 }
 
-template <int NIMG, int KW, int QB>
+template <int NIMG, int KW, int QB, bool GATHER>
 static int wgrad_cl_launch(const WgradClParams& p, int blocks, hipStream_t stream, const __bf16* Pt, const __bf16* Qt, float* part) {
     constexpr int PR8 = (32 + KW - 1 + 7) / 8, QPAN = (QB * 16 + 63) / 64;
     constexpr int LDS_BYTES = 2 * (NIMG * PR8 + QPAN * 4) * 1024;
-    static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_cl_kernel<NIMG, KW, QB>,
+    static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_cl_kernel<NIMG, KW, QB, GATHER>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (attr != hipSuccess) return ZSV_E_LAUNCH;
-    hipLaunchKernelGGL((wgrad_cl_kernel<NIMG, KW, QB>), dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, p, Pt, Qt, part);
+    hipLaunchKernelGGL((wgrad_cl_kernel<NIMG, KW, QB, GATHER>), dim3((unsigned)blocks), dim3(256), LDS_BYTES, stream, p, Pt, Qt, part);
     return launch_status();
 }
 
@@ -397,13 +440,20 @@ int zsv_conv3d_bf16_wgrad(const zsv_conv_desc* d, const void* x, const void* dz,
     if (!x || !dz || !dw || !workspace) return ZSV_E_NULL;
     if (workspace_bytes < (size_t)pl.slices * pl.taps * pl.Ptot * pl.Qpad * sizeof(float)) return ZSV_E_WORKSPACE;
     WgradClParams p;
-    p.P = d->N * d->Ti * d->Hi * d->Wi;
-    p.T = d->Ti; p.H = d->Hi; p.W = d->Wi;
-    p.mW = make_magic((unsigned)d->Wi); p.mH = make_magic((unsigned)d->Hi); p.mT = make_magic((unsigned)d->Ti);
+    const bool gather = pl.mode >= 2;
+    p.P = (int)pl.rows;
+    p.T = gather ? d->To : d->Ti; p.H = gather ? d->Ho : d->Hi; p.W = gather ? d->Wo : d->Wi;
+    p.mW = make_magic((unsigned)p.W); p.mH = make_magic((unsigned)p.H); p.mT = make_magic((unsigned)p.T);
     p.ppitch = pl.ppitch; p.qpitch = pl.qpitch;
-    p.pW = d->pW;
-    p.sgn = pl.mode == 0 ? 1 : -1;
+    const long in_vox = (long)d->N * d->Ti * d->Hi * d->Wi;
+    const unsigned x_bytes = (unsigned)(in_vox * rup(d->Cin, 32) * 2), dz_bytes = (unsigned)(pl.rows * rup(d->Cout, 32) * 2);
+    p.p_bytes = pl.mode == 1 ? dz_bytes : x_bytes;
+    p.q_bytes = pl.mode == 1 ? x_bytes : dz_bytes;
+    p.pW = gather ? 0 : d->pW;
+    p.sgn = pl.mode == 1 ? -1 : 1;
     p.kH = d->kH; p.pT = d->pT; p.pH = d->pH;
+    p.kW3 = d->kW; p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pWg = d->pW;
+    p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi;
     p.qgroups = pl.qgroups; p.ppanels = pl.ppanels; p.imggroups = pl.imggroups;
     p.taps = pl.taps;
     p.chunks = pl.chunks; p.chunks_per_slice = pl.chunks_per_slice;
@@ -411,13 +461,19 @@ int zsv_conv3d_bf16_wgrad(const zsv_conv_desc* d, const void* x, const void* dz,
     const int blocks = pl.slices * pl.imggroups * pl.ppanels * pl.qgroups;
     hipStream_t s = (hipStream_t)stream;
     float* part = (float*)workspace;
+    const __bf16 *xb = (const __bf16*)x, *zb = (const __bf16*)dz;
     int st;
-    if (pl.mode == 0) st = wgrad_cl_launch<3, 3, 3>(p, blocks, s, (const __bf16*)x, (const __bf16*)dz, part);
-    else st = wgrad_cl_launch<3, 1, 9>(p, blocks, s, (const __bf16*)dz, (const __bf16*)x, part);
+    switch (pl.mode) {
+        case 0: st = wgrad_cl_launch<3, 3, 3, false>(p, blocks, s, xb, zb, part); break;
+        case 1: st = wgrad_cl_launch<3, 1, 9, false>(p, blocks, s, zb, xb, part); break;
+        case 2: st = wgrad_cl_launch<9, 1, 3, true>(p, blocks, s, xb, zb, part); break;
+        case 3: st = wgrad_cl_launch<3, 1, 9, true>(p, blocks, s, xb, zb, part); break;
+        default: st = wgrad_cl_launch<1, 1, 9, true>(p, blocks, s, xb, zb, part); break;
+    }
     if (st != ZSV_OK) return st;
     const long total = (long)pl.taps * pl.Pch * pl.Qch;
     hipLaunchKernelGGL(wgrad_cl_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, part, pl.slices, pl.taps, pl.Ptot,
-                       pl.Qpad, pl.Pch, pl.Qch, pl.mode == 0 ? 1 : 0, dw);
+                       pl.Qpad, pl.Pch, pl.Qch, pl.mode == 1 ? 0 : 1, dw);
     return launch_status();
 }
 
