@@ -497,3 +497,46 @@ def test_c3d_autocast_training_step_against_the_reference_under_cpu_autocast():
     losses = [train.train_step(model, opt, crit, x, z, scaler=scaler, autocast=True)[1] for _ in range(6)]
     torch.cuda.synchronize()
     assert losses[-1].item() < losses[0].item()
+
+
+def test_graph_mode_replays_the_same_step_bit_for_bit():
+    """amp.autocast(graph=True): the bf16 trunk's forward and backward captured as two hipGraphs (amp._GraphedTrunk).  Four Adam steps
+    through the graphs equal four eager steps bit for bit -- losses, every gradient of the last step, every parameter and BatchNorm
+    buffer afterwards (the capture's warm-up runs must not leak into the running statistics) -- and a second graphed forward before
+    the first one's backward is refused."""
+    model, weights = _model()
+    x = synthetic.synthetic_clips(3, 8, 56).to(DEV)
+    _, z = synthetic.synthetic_targets(3)
+    z = z.to(DEV)
+    crit = torch.nn.MSELoss()
+
+    def run(graph):
+        model.load_state_dict(weights)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(4):
+            _, loss = train.train_step(model, opt, crit, x, z, autocast=True, graph=graph)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        return torch.stack(losses), grads, {k: v.clone() for k, v in model.state_dict().items()}
+
+    la, ga, sa = run(False)
+    lb, gb, sb = run(True)
+    assert "_graphs" in amp.train_path_for(model.model).__dict__
+    assert torch.equal(la, lb)
+    assert sorted(ga) == sorted(gb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    lc, _, sc = run(True)                                   # the captured graphs are reused: same again
+    assert torch.equal(la, lc)
+    model.zero_grad(set_to_none=True)
+    with amp.autocast(graph=True):
+        y1, _ = model(x)
+        y2, _ = model(x)                                    # overwrites the first forward's tape
+    with pytest.raises(RuntimeError, match="one forward per backward"):
+        y1.sum().backward()
+    y2.sum().backward()                                     # the latest forward's backward is fine

@@ -20,6 +20,7 @@ ap.add_argument("--size", type=int, default=112)
 ap.add_argument("--network", default="r2plus1d_18")
 ap.add_argument("--fp32", action="store_true", help="time the fp32 step instead (same loop)")
 ap.add_argument("--optimizer", choices=["torch", "fused"], default="torch")
+ap.add_argument("--graph", action="store_true", help="the bf16 trunk as two hipGraphs (amp.autocast(graph=True))")
 args = ap.parse_args()
 dev = torch.device("cuda")
 model = network.get_network(SimpleNamespace(network=args.network, fixconvs=False, nopretrained=False))
@@ -34,7 +35,7 @@ pacer = train.StepPacer(2)
 
 
 def step():
-    return train.train_step(model, opt, crit, x, z, pacer=pacer, autocast=not args.fp32)[1]
+    return train.train_step(model, opt, crit, x, z, pacer=pacer, autocast=not args.fp32, graph=args.graph)[1]
 
 
 for _ in range(3):

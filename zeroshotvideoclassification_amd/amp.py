@@ -29,6 +29,7 @@ There is no CPU fallback.
 """
 from __future__ import annotations
 
+import os
 import threading
 from ctypes import byref, c_void_p
 from typing import List, Optional
@@ -50,23 +51,32 @@ class autocast:
     ``network.Model`` over a VideoResNet trunk runs its trunk in bf16 (this module); in eval mode it runs the bf16 inference
     engine.  ``dtype`` must be ``torch.bfloat16`` (fp16 is not implemented: bf16 is the native 16-bit type here)."""
 
-    def __init__(self, enabled: bool = True, dtype: torch.dtype = torch.bfloat16):
+    def __init__(self, enabled: bool = True, dtype: torch.dtype = torch.bfloat16, graph: Optional[bool] = None):
+        """``graph``: run the VideoResNet trunk's bf16 forward and backward as two hipGraphs (captured once per clip shape: the
+        trunk's ~560 launches per step become two graph launches; one forward per backward).  Default: the ``ZSV_AMP_GRAPH``
+        environment variable (off)."""
         if enabled and dtype != torch.bfloat16:
             raise RuntimeError(f"amp.autocast: dtype {dtype} is not supported (bf16 only)")
         self.enabled = bool(enabled)
+        self.graph = bool(int(os.environ.get("ZSV_AMP_GRAPH", "0") or 0)) if graph is None else bool(graph)
 
     def __enter__(self):
-        self.prev = getattr(_state, "enabled", False)
+        self.prev = (getattr(_state, "enabled", False), getattr(_state, "graph", False))
         _state.enabled = self.enabled
+        _state.graph = self.enabled and self.graph
         return self
 
     def __exit__(self, *exc):
-        _state.enabled = self.prev
+        _state.enabled, _state.graph = self.prev
         return False
 
 
 def is_autocast_enabled() -> bool:
     return getattr(_state, "enabled", False)
+
+
+def is_graph_enabled() -> bool:
+    return getattr(_state, "graph", False)
 
 
 # ---- channels-last bf16 primitives -----------------------------------------------------------------------------------
@@ -258,7 +268,7 @@ class Bf16TrainPath:
         n, t, h, w, _ = x.shape
         d = u.desc(n, t, h, w, wo)
         blob = pack_conv(d, u.conv.weight.detach(), None, None)
-        timer = ops.KERNEL_TIMER
+        timer = None if torch.cuda.is_current_stream_capturing() else ops.KERNEL_TIMER      # (timing events cannot be captured)
         mark = timer.start() if timer is not None and timer.wants("conv_bf16_fwd", d) else None
         z = conv_bf16(d, x, blob, None, False)
         if mark is not None:
@@ -555,6 +565,93 @@ def c3d_features(model: nn.Module, clips: torch.Tensor) -> torch.Tensor:
     return _C3DTrunkBf16.apply(clips, path, torch.is_grad_enabled(), *path.params)
 
 
+class _GraphedTrunk:
+    """The bf16 trunk's forward and backward as two hipGraphs (``torch.cuda.CUDAGraph``) for ONE clip shape: every launch of
+    ``Bf16TrainPath.forward`` / ``.backward`` -- weight packs, convolutions, BatchNorm passes, the weight gradients forked to
+    the side stream and joined at the end -- is captured once; a step replays the two graphs (12 us of host time each instead of
+    ~8 ms of Python per pass, and no launch gaps on the device).  Inputs and outputs are static buffers: the clip is copied in,
+    the pooled feature and the parameter gradients are copied out.  The kernels read the parameters, BatchNorm running
+    statistics and counters through their (fixed) addresses, so the optimizer's updates are seen by the next replay.  One
+    forward per backward: a second graphed forward before the first one's backward would overwrite its tape (checked)."""
+
+    def __init__(self, path: "Bf16TrainPath", clips: torch.Tensor):
+        self.path = path
+        self.shape = tuple(clips.shape)
+        dev = clips.device
+        self.clips = clips.detach().clone()
+        self.generation = 0
+        bns = [u.bn for u in path.units]
+        saved = [(bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()) for bn in bns if bn.running_mean is not None]
+
+        def forward_body():
+            tape = []
+            _state.nbt_pending = []
+            try:
+                feat = path.forward(self.clips, tape)
+            finally:
+                pending, _state.nbt_pending = _state.nbt_pending, None
+            if pending:
+                torch._foreach_add_(pending, 1)
+            return tape, feat, meanpool_bf16(feat, path.features)
+
+        def backward_body(tape, feat, dpooled):
+            dfeat = meanpool_bf16_bwd(dpooled, feat, path.features)
+            with ops.deferred_wgrad_join():
+                grads = path.backward(tape, dfeat)
+            ops.join_wgrad_streams()
+            return grads
+
+        # warm-up on a side stream (one-time kernel attribute calls, allocator): it really runs, so the BatchNorm buffers are put back
+        cur = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                tape, feat, pooled = forward_body()
+                backward_body(tape, feat, torch.zeros_like(pooled))
+            del tape, feat, pooled
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            i = 0
+            for bn in bns:
+                if bn.running_mean is not None:
+                    bn.running_mean.copy_(saved[i][0]); bn.running_var.copy_(saved[i][1]); bn.num_batches_tracked.copy_(saved[i][2])
+                    i += 1
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.tape, self.feat, self.pooled = forward_body()
+        self.dpooled = torch.zeros_like(self.pooled)
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
+            self.grads = backward_body(self.tape, self.feat, self.dpooled)
+        self.grad_list = [self.grads.get(id(p)) for p in path.params]
+
+    def forward(self, clips: torch.Tensor) -> torch.Tensor:
+        self.clips.copy_(clips)
+        self.fwd_graph.replay()
+        self.generation += 1
+        return self.pooled.clone()
+
+    def backward(self, dpooled: torch.Tensor, generation: int, needs):
+        if generation != self.generation:
+            raise RuntimeError("amp (graph mode): the graphed trunk ran forward again before this backward -- one forward per backward; "
+                               "use amp.autocast(graph=False) for several forwards per backward pass")
+        self.dpooled.copy_(dpooled)
+        self.bwd_graph.replay()
+        # the gradients live in the graph's static buffers: hand autograd copies (one flat buffer, one multi-tensor copy)
+        src = [g for g, need in zip(self.grad_list, needs) if g is not None and need]
+        flat = torch.empty(sum(g.numel() for g in src), dtype=torch.float32, device=dpooled.device)
+        views, off = [], 0
+        for g in src:
+            views.append(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        if src:
+            torch._foreach_copy_(views, src)
+        it = iter(views)
+        return [next(it) if (g is not None and need) else None for g, need in zip(self.grad_list, needs)]
+
+
 def train_path_for(trunk: nn.Module) -> Bf16TrainPath:
     path = trunk.__dict__.get("_zsv_bf16_train_path")
     if path is None:
@@ -569,6 +666,18 @@ class _TrunkBf16(Function):
     @staticmethod
     def forward(ctx, clips, path, record, *params):
         ops._require(clips)
+        ctx.graphed = None
+        if record and is_graph_enabled() and all(p.requires_grad for p in params):
+            graphs = path.__dict__.setdefault("_graphs", {})
+            key = (tuple(clips.shape), clips.device.index)
+            with torch.cuda.device(clips.device):
+                g = graphs.get(key)
+                if g is None:
+                    g = graphs[key] = _GraphedTrunk(path, clips.contiguous())
+                pooled = g.forward(clips)
+            ctx.graphed, ctx.generation, ctx.n_params = g, g.generation, len(params)
+            ctx.set_materialize_grads(False)
+            return pooled
         # (`record`: grad mode at the call site -- inside a Function's forward it is always off; no tape under torch.no_grad())
         tape = [] if record and any(p.requires_grad for p in params) else None
         with torch.cuda.device(clips.device):
@@ -588,6 +697,12 @@ class _TrunkBf16(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dpooled):
+        if ctx.graphed is not None:
+            if dpooled is None:
+                return (None, None, None) + (None,) * ctx.n_params
+            with torch.cuda.device(dpooled.device):
+                out = ctx.graphed.backward(dpooled.float(), ctx.generation, ctx.needs_input_grad[3:])
+            return (None, None, None) + tuple(out)
         path, tape = ctx.path, ctx.tape
         if dpooled is None or tape is None:
             return (None, None, None) + (None,) * ctx.n_params

@@ -146,9 +146,26 @@ def _on_wgrad_stream(launch, inputs, param=None):
     for t in inputs:
         t.record_stream(side)                          # the side stream reads memory the backward stream owns
     dw.record_stream(main)                             # ... and the optimizer reads dw on the backward stream
+    if getattr(_call_state, "defer_wgrad_join", False):
+        return dw                                      # (the caller joins the side stream itself: hipGraph capture of a whole backward, amp.py)
     if _dw_read_early(param, dev) or not _queue_wgrad_join(dev):
         main.wait_stream(side)
     return dw
+
+
+class deferred_wgrad_join:
+    """Inside this context weight-gradient launches fork to the side stream and nobody waits for them: the caller joins once
+    at the end (``join_wgrad_streams()``).  Used while a whole backward is captured into a hipGraph, where the per-pass
+    autograd callback does not exist."""
+
+    def __enter__(self):
+        self.prev = getattr(_call_state, "defer_wgrad_join", False)
+        _call_state.defer_wgrad_join = True
+        return self
+
+    def __exit__(self, *exc):
+        _call_state.defer_wgrad_join = self.prev
+        return False
 
 
 def _queue_wgrad_join(device) -> bool:

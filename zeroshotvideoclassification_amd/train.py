@@ -92,7 +92,7 @@ class StepPacer:
 
 def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criterion, x: torch.Tensor,
                z: torch.Tensor, grad_sync=None, scaler=None, pacer: Optional[StepPacer] = None,
-               autocast: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+               autocast: bool = False, graph: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """One iteration of main.py:170-203.  ``grad_sync`` (a ``ddp.GradientSync``) all-reduces the
     gradients across ranks, overlapped with backward, before the optimizer step.  ``scaler`` (an
     ``optim.LossScaler`` or a ``torch.cuda.amp.GradScaler``) reproduces main.py:195-203:
@@ -108,7 +108,7 @@ def train_step(model: torch.nn.Module, optimizer: torch.optim.Optimizer, criteri
         grad_sync.begin_step()
     if autocast:
         from . import amp
-        with amp.autocast():
+        with amp.autocast(graph=graph):           # graph=True: the bf16 trunk as two hipGraphs (amp._GraphedTrunk)
             y = embed(model, x)
             loss = criterion(y, z)
     else:
