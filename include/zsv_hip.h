@@ -296,11 +296,12 @@ int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t 
 int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
                   const float* save_invstd, const float* fwd_coef, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta,
                   void* workspace, size_t workspace_bytes, void* stream);
-/* Weight gradient of a stride-1 "same" convolution from channels-last bf16 operands (x [N][T][H][W][CinP], dz
- * [N][T][H][W][CoutP]) with fp32 accumulation: dw (Cout, Cin, kT, kH, kW) fp32 -- aten::convolution_backward's weight
- * gradient under autocast (resnet.py:40-52 1x3x3 / 3x1x1, resnet.py:23-30 3x3x3).  The workspace holds per-slice partial
- * sums; zsv_conv3d_bf16_wgrad_workspace_bytes() == 0 means "not this kernel's geometry" (strided, 1x1x1, the clip
- * convolution): the caller converts the operands (below) and uses zsv_conv3d_wgrad. */
+/* Weight gradient of a convolution from channels-last bf16 operands (x [N][Ti][Hi][Wi][CinP], dz [N][To][Ho][Wo][CoutP]) with
+ * fp32 accumulation: dw (Cout, Cin, kT, kH, kW) fp32 -- aten::convolution_backward's weight gradient under autocast
+ * (resnet.py:40-52 1x3x3 / 3x1x1 incl. the strided ones, resnet.py:23-30 3x3x3, resnet.py:270 1x1x1).  The workspace holds
+ * per-slice partial sums; zsv_conv3d_bf16_wgrad_workspace_bytes() == 0 means "not this kernel's geometry" (the clip
+ * convolution, other kernel shapes, tensors of 4 GiB and more): the caller converts the operands (below) and uses
+ * zsv_conv3d_wgrad. */
 size_t zsv_conv3d_bf16_wgrad_workspace_bytes(const zsv_conv_desc* d);
 int zsv_conv3d_bf16_wgrad(const zsv_conv_desc* d, const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
                           void* stream);

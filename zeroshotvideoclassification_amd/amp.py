@@ -261,7 +261,7 @@ class Bf16TrainPath:
         # parameter order of the autograd Function: weight, gamma, beta per unit
         self.params = []
         for u in units:
-            self.params += [u.conv.weight, u.bn.weight, u.bn.bias]
+            self.params += [p for p in (u.conv.weight, u.bn.weight, u.bn.bias) if p is not None]      # (affine=False: no gamma / beta)
 
     # -- forward -------------------------------------------------------------------------------------------------------
     def _unit_fwd(self, u: _Unit, x: torch.Tensor, tape, residual=None, clips=None, wo=None):
@@ -421,8 +421,10 @@ class Bf16TrainPath:
             idx -= 1
             u = r.unit
             dz, g, dgamma, dbeta = bn_cl_bwd(dy, r.y, r.z, u.bn, r.mean, r.invstd, u.relu, want_g, fwd_coef=r.coef)
-            grads[id(u.bn.weight)] = dgamma
-            grads[id(u.bn.bias)] = dbeta
+            if u.bn.weight is not None:
+                grads[id(u.bn.weight)] = dgamma
+            if u.bn.bias is not None:
+                grads[id(u.bn.bias)] = dbeta
             if need_weight_grads and u.conv.weight.requires_grad:
                 grads[id(u.conv.weight)] = self._wgrad(r, dz)
             dx = self._dgrad(r, dz) if need_dx else None
@@ -673,6 +675,8 @@ class _TrunkBf16(Function):
             with torch.cuda.device(clips.device):
                 g = graphs.get(key)
                 if g is None:
+                    while len(graphs) >= 2:                     # (a captured pair keeps its whole tape in a private pool: two shapes at most)
+                        graphs.pop(next(iter(graphs)))
                     g = graphs[key] = _GraphedTrunk(path, clips.contiguous())
                 pooled = g.forward(clips)
             ctx.graphed, ctx.generation, ctx.n_params = g, g.generation, len(params)

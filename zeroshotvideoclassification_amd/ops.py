@@ -193,11 +193,15 @@ def _queue_wgrad_join(device) -> bool:
 # of the weight-gradient queue's kernels).  The table depends on (input extents, kernel, padding) only: one
 # per geometry and stream is kept here (a few hundred KB each) and handed to zsv_conv3d_wgrad_masked.
 _WGRAD_MASKS = {}
+_WGRAD_MASKS_GEN = [None]
 
 
 def _wgrad_mask(d: ConvDesc, device, stream: c_void_p):
     if os.environ.get("ZSV_NO_WGRAD_MASK_CACHE"):
         return None
+    if _WGRAD_MASKS_GEN[0] != _lib.knob_generation():        # the switches changed: which kernel serves a geometry may have too
+        _WGRAD_MASKS.clear()
+        _WGRAD_MASKS_GEN[0] = _lib.knob_generation()
     # (the table's CONTENT depends on extents / kernel / padding only; whether a geometry's kernel reads one depends on all of it)
     key = (torch.device(device).index, stream.value, _lib.knob_generation()) + tuple(getattr(d, f) for f, _ in ConvDesc._fields_)
     hit = _WGRAD_MASKS.get(key)
