@@ -654,6 +654,8 @@ WGRAD_WINO_CASES = [
     ("m64_14x14", 22, 32, (4, 14, 14), 64, 1),                  # 64-row tile with the edge handling
     ("partial_chunk_aligned_w", 24, 16, (3, 20, 12), 128, 1),  # S = 720 = 22.5 chunks, W % 4 = 0
     ("unaligned_w_whole_chunks", 28, 16, (4, 16, 10), 128, 1), # S = 640 = 20 chunks, W % 4 = 2
+    ("two_144_row_tiles", 6, 32, (4, 28, 28), 288, 1),         # F(4,3) form: 5 + 4 row blocks per workgroup, two row tiles
+    ("m200_ragged_second_tile", 12, 48, (2, 24, 32), 200, 3),   # F(4,3) form: 144 + 56 rows, 9 row taps
 ]
 
 
@@ -677,6 +679,11 @@ def test_conv3d_wgrad_winograd_path(case, monkeypatch):
     a = run()
     close(a, ref, what=f"{name} wgrad (winograd)")
     assert torch.equal(a, run()), "bitwise reproducible"
+    if w % 4 == 0 and (t * h * w) % 32 == 0 and cout > 64:      # the F(4,3) form (conv_wgrad_wino4_kernel) took it: also the F(2,3) form
+        monkeypatch.setenv("ZSV_NO_WGRAD_WINO4", "1")
+        a2 = run()
+        close(a2, ref, what=f"{name} wgrad (winograd, F(2,3) form)")
+        assert not torch.equal(a, a2), "F(4,3) and F(2,3) forms should not be the same kernel"
     monkeypatch.setenv("ZSV_NO_WGRAD_WINO", "1")
     b = run()
     close(b, ref, what=f"{name} wgrad (plain)")

@@ -48,6 +48,7 @@
     X(WGRAD_WINO_SLICES) \
     X(NO_WINO) \
     X(NO_WGRAD_WINO) \
+    X(NO_WGRAD_WINO4) \
     X(WINO_MIN_TILES) \
     X(WINO_NO_SPLITK) \
     X(NO_WINOT) \
