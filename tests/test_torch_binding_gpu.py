@@ -1,0 +1,95 @@
+"""The torch-extension layer (csrc/torch_binding.cpp, `torch.ops.zsv.*`) against the ctypes binding of the same C ABI (bit for bit:
+both call the same entry points) and against torch CPU fp64."""
+import pytest
+import torch
+
+from zeroshotvideoclassification_amd import ops, torch_ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+CASES = [
+    # name, N, Cin, (T, H, W), Cout, kernel, stride, padding
+    ("spatial_s1", 2, 16, (4, 28, 28), 45, (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    ("temporal_s1", 2, 45, (4, 14, 14), 32, (3, 1, 1), (1, 1, 1), (1, 0, 0)),
+    ("spatial_s2", 2, 16, (2, 28, 28), 40, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    ("full_333", 1, 8, (4, 12, 12), 24, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    ("pointwise_s2", 2, 16, (4, 8, 8), 32, (1, 1, 1), (2, 2, 2), (0, 0, 0)),
+]
+
+
+def close(a, ref, rtol=2e-5, what=""):
+    a = a.detach().double().cpu()
+    err = (a - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+    assert err <= rtol, f"{what}: max err {err:.3e} of the range"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv3d_operator(case):
+    name, n, cin, (t, h, w), cout, k, s, p = case
+    ns = torch_ops.load()
+    g = torch.Generator().manual_seed(len(name) + 7 * cin)
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (v.double().requires_grad_() for v in (x, wt, b))
+    yr = torch.nn.functional.conv3d(xr, wr, br, s, p)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+
+    xd, wd, bd = (v.to(DEV).requires_grad_() for v in (x, wt, b))
+    y = ns.conv3d(xd, wd, bd, list(s), list(p))
+    y.backward(gy.to(DEV))
+    close(y, yr.detach(), what="torch.ops.zsv.conv3d forward")
+    close(xd.grad, xr.grad, what="input gradient")
+    close(wd.grad, wr.grad, what="weight gradient")
+    close(bd.grad, br.grad, what="bias gradient")
+
+    # the ctypes binding of the same entry points: identical bits
+    xc, wc = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_()
+    yc = ops.conv3d(xc, wc, None, s, p)
+    yc.backward(gy.to(DEV))
+    y0 = ns.conv3d_fwd(x.to(DEV), wt.to(DEV), None, list(s), list(p), False)
+    assert torch.equal(y0, yc.detach()), "forward differs between the two bindings"
+    assert torch.equal(ns.conv3d_dgrad(gy.to(DEV), wt.to(DEV), list(x.shape), list(s), list(p)), xc.grad)
+    assert torch.equal(ns.conv3d_wgrad(x.to(DEV), gy.to(DEV), list(wt.shape), list(s), list(p)), wc.grad)
+    with torch.inference_mode():
+        assert torch.equal(ns.conv3d(x.to(DEV), wt.to(DEV), None, list(s), list(p)), y0)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_batch_norm_relu_operator(relu):
+    ns = torch_ops.load()
+    g = torch.Generator().manual_seed(11 + relu)
+    x = torch.randn(3, 24, 4, 10, 12, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g) * 0.1
+    gy = torch.randn(x.shape, generator=g)
+    bn = torch.nn.BatchNorm3d(24).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    xr = x.double().requires_grad_()
+    yr = bn(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(gy.double())
+
+    xd = x.to(DEV).requires_grad_()
+    gd, bd = gamma.to(DEV).requires_grad_(), beta.to(DEV).requires_grad_()
+    rm, rv = torch.zeros(24, device=DEV), torch.ones(24, device=DEV)
+    y = ns.batch_norm_relu(xd, gd, bd, rm, rv, 0.1, 1e-5, relu)
+    y.backward(gy.to(DEV))
+    close(y, yr.detach(), what="batch_norm_relu forward")
+    close(xd.grad, xr.grad, rtol=1e-4, what="dx")
+    close(gd.grad, bn.weight.grad, rtol=1e-4, what="dgamma")
+    close(bd.grad, bn.bias.grad, rtol=1e-4, what="dbeta")
+    close(rm, bn.running_mean, what="running_mean")
+    close(rv, bn.running_var, what="running_var")
+
+
+def test_errors_name_the_status():
+    ns = torch_ops.load()
+    with pytest.raises(RuntimeError, match="channels"):
+        ns.conv3d_fwd(torch.zeros(1, 3, 2, 4, 4, device=DEV), torch.zeros(4, 5, 1, 3, 3, device=DEV), None, [1, 1, 1], [0, 1, 1], False)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ns.conv3d_fwd(torch.zeros(1, 3, 2, 4, 8, device=DEV)[..., ::2], torch.zeros(4, 3, 1, 3, 3, device=DEV), None, [1, 1, 1], [0, 1, 1], False)

@@ -529,6 +529,177 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
 #endif
 }
 
+// The same convolution with ONE image per (kt, chunk) for all nine (kh, kw) taps (round 4).  The images of kh = 0, 1, 2 are the
+// same rows shifted by W: for a 256-column tile they overlap in all but 2 W rows, and the kernels on these layers run at the
+// rate L2 -> LDS delivers (~4 TB/s over the chip for the forward AND for the 64-row input gradient, whose steps are three
+// times as many and a third as long -- making its steps fatter changed nothing).  Rows n0 + (kt-pT) HW - W - 1 ... + BN + 2 W + 1
+// are staged once (NI_P pieces: 24 for W <= 63, 20 for W <= 31); the fragment of tap (kh, kw) is read at row offset kh W + kw
+// (the slot swizzle is conflict-free at any start row).  Image bytes per tile: 370 instead of 3 x 258 rows for W = 56.
+template <int TM, int TN, int WGM, int WGN, int NI_P>
+__global__ __launch_bounds__(256, 2) void conv_bf16_same9_kernel(Bf16Params prm, const __bf16* __restrict__ X,
+                                                                const __bf16* __restrict__ Wp,
+                                                                const float* __restrict__ shift,
+                                                                const __bf16* __restrict__ R, __bf16* __restrict__ Y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGM == 1 || (TM % 2) == 0, "row-block pairs must not straddle waves");
+    constexpr int KW = 3;
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int NA_P = BM / 16;                                     // 1-KiB pieces of an A stage (NI_P: of the image)
+    constexpr int KHW = 9;
+    constexpr int NAW = (NA_P + 3) / 4, NIW = (NI_P + 3) / 4;
+    constexpr int A_STAGE = BM * 64, IMG = NI_P * 1024;
+    constexpr int IMG_AT = 3 * A_STAGE, SHIFT_AT = IMG_AT + 2 * IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int tile = xcd_tile(gridDim.x, blockIdx.x);
+    const int tm = tile % prm.tiles_m, tn = tile / prm.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int srcslot = ((lane & 3) ^ swz(lane >> 2)) * 8;
+    int a_off[NAW], a_dst[NAW];
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        int pa = wave + 4 * k;
+        if (pa >= NA_P) pa -= 4;
+        a_off[k] = (pa * 16 + (lane >> 2)) * 32 + srcslot;
+        a_dst[k] = pa * 1024;
+    }
+    int i_row[NIW], i_dst[NIW];                      // image row this lane fills, per piece
+#pragma unroll
+    for (int k = 0; k < NIW; ++k) {
+        int pi = wave + 4 * k;
+        if (pi >= NI_P) pi -= 4;
+        const int r = pi * 16 + (lane >> 2);
+        i_row[k] = r < BN + 2 * prm.Wo + 2 ? n0 + r : -(1 << 30);    // rows past the last tap's last column: not fetched
+        i_dst[k] = pi * 1024;
+    }
+    // border masks of this lane's 4 columns: bit tap = the tap reads inside the input.  One decode,
+    // then +16 voxels per column block (carry into h, t).
+    unsigned mask[TN];
+    {
+        const int p0 = n0 + wn * TN * 16 + (lane & 15);
+        int rem = p0 % prm.ToHoWo;
+        int t = rem / prm.HoWo;
+        rem -= t * prm.HoWo;
+        int h = rem / prm.Wo, w = rem - h * prm.Wo;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            unsigned m = 0;
+            if (p0 + 16 * j < prm.P) {
+                unsigned mt = 0, mh = 0, mw = 0;
+                for (int a = 0; a < prm.kT; ++a) mt |= (unsigned)((unsigned)(t + a - prm.pT) < (unsigned)prm.Ti) << a;
+                for (int b = 0; b < prm.kH; ++b) mh |= (unsigned)((unsigned)(h + b - prm.pH) < (unsigned)prm.Hi) << b;
+                for (int c = 0; c < KW; ++c) mw |= (unsigned)((unsigned)(w + c - prm.pW) < (unsigned)prm.Wi) << c;
+                int tap = 0;
+                for (int a = 0; a < prm.kT; ++a)
+                    for (int b = 0; b < prm.kH; ++b, tap += KW)
+                        if (((mt >> a) & (mh >> b)) & 1u) m |= mw << tap;
+            }
+            mask[j] = m;
+            w += 16;
+            while (w >= prm.Wo) {
+                w -= prm.Wo;
+                if (++h == prm.Hi) { h = 0; if (++t == prm.Ti) t = 0; }
+            }
+        }
+    }
+    const __bf16* zero = (const __bf16*)zsv_zero_line;
+    const size_t wq_step = (size_t)prm.Mp * 32;
+    const __bf16* w_tile = Wp + (size_t)m0 * 32;
+
+    // step = (kt, chunk cc, kh, kw); image = (kt, cc): rows n0 + (kt-pT)*HW - W - 1 ... + BN + 2W + 1 serve all nine taps
+    const int nimg = prm.kT * prm.nchunk;
+    const int nsteps = nimg * KHW;
+    int a_kt = 0, a_cc = 0, a_t9 = 0;                // walk of the A issue
+    auto issue_a = [&](int buf) {
+        const __bf16* wq = w_tile + (size_t)((a_kt * KHW + a_t9) * prm.nchunk + a_cc) * wq_step;
+        unsigned char* base = lds + buf * A_STAGE;
+#pragma unroll
+        for (int k = 0; k < NAW; ++k) __builtin_amdgcn_global_load_lds(wq + a_off[k], (lds_ptr_t)(base + a_dst[k]), 16, 0, 0);
+        if (++a_t9 == KHW) {
+            a_t9 = 0;
+            if (prm.cc_outer) {
+                if (++a_kt == prm.kT) { a_kt = 0; ++a_cc; }
+            } else if (++a_cc == prm.nchunk) { a_cc = 0; ++a_kt; }
+        }
+    };
+    int b_kt = 0, b_cc = 0;                          // walk of the B image issue
+    auto issue_b = [&](int buf) {
+        const int shift_rows = (b_kt - prm.pT) * prm.HoWo - prm.pH * prm.Wo - prm.pW;
+        unsigned char* base = lds + IMG_AT + buf * IMG;
+#pragma unroll
+        for (int k = 0; k < NIW; ++k) {
+            const int src = i_row[k] + shift_rows;
+            const __bf16* ptr = (unsigned)src < (unsigned)prm.P ? X + ((size_t)src * prm.sW + b_cc * 32 + srcslot) : zero;
+            __builtin_amdgcn_global_load_lds(ptr, (lds_ptr_t)(base + i_dst[k]), 16, 0, 0);
+        }
+        if (prm.cc_outer) {
+            if (++b_kt == prm.kT) { b_kt = 0; ++b_cc; }
+        } else if (++b_cc == prm.nchunk) { b_cc = 0; ++b_kt; }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const unsigned a_frag = lds_base + wm * TM * 16 * 64 + (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    unsigned b_frag[KHW];                            // fragment base per (kh, kw): rows (l&15) + kh*W + kw of the column block
+#pragma unroll
+    for (int c = 0; c < KHW; ++c) {
+        const int x = (lane & 15) + (c / KW) * prm.Wo + c % KW;
+        b_frag[c] = lds_base + IMG_AT + (wn * TN * 16 + x) * 64 + (((lane >> 4) ^ swz(x)) << 4);
+    }
+
+    if (wave == 0) {
+        const int l4 = lane < BM / 4 ? lane : BM / 4 - 1;
+        __builtin_amdgcn_global_load_lds(shift + m0 + 4 * l4, (lds_ptr_t)(lds + SHIFT_AT), 16, 0, 0);
+    }
+    issue_b(0);
+    issue_a(0);
+    issue_a(1);                                      // nsteps >= 3
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int abuf = 0, abuf2 = 2;
+    int kt = 0, cc = 0;
+    for (int img = 0; img < nimg; ++img) {
+        const unsigned img_off = (img & 1) * IMG;
+        const int tap = kt * KHW;
+#pragma unroll
+        for (int c = 0; c < KHW; ++c) {
+            const int step = img * KHW + c;
+            const bool more_a = step + 2 < nsteps;
+            const bool more_b = c == KHW - 3 && img + 1 < nimg;  // three steps ahead, as the per-(kt,kh) images were
+            if (more_a) issue_a(abuf2);              // A first: the image issued after it may stay in flight
+            if (more_b) issue_b((img + 1) & 1);
+            const int tp = tap + c;
+            unsigned keepv[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) keepv[j] = (mask[j] >> tp) & 1u;
+            mfma_step<TM, TN, true>(acc, a_frag + abuf * A_STAGE, b_frag[c] + img_off, keepv);
+            // A(step+1) -- and before an image's first step the image -- must have landed, for every wave.  In issue order
+            // the next image sits between A(step+1) and A(step+2) for two steps: it may stay in flight there.
+            if ((c == KHW - 3 || c == KHW - 2) && img + 1 < nimg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW + NIW) : "memory");
+            else if (more_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NAW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            abuf = abuf == 2 ? 0 : abuf + 1;
+            abuf2 = abuf2 == 2 ? 0 : abuf2 + 1;
+        }
+        if (prm.cc_outer) {
+            if (++kt == prm.kT) { kt = 0; ++cc; }
+        } else if (++cc == prm.nchunk) { cc = 0; ++kt; }
+    }
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
+#endif
+}
+
 // Temporal 3x1x1 stride-1 convolutions (Conv2Plus1D's second half, resnet.py:50-52): the workgroup tile
 // is TT output frames x HB (h,w) positions (TT * HB = 256 columns), so ONE LDS image of TT+2 input
 // frames x HB positions serves the three taps -- a tap is a shift of HB rows, always 16-row aligned --
@@ -835,6 +1006,38 @@ static int bf16_same_launch(Bf16Params& p, hipStream_t stream, const __bf16* x, 
     return launch_status();
 }
 
+template <int TM, int TN, int WGM, int WGN, int NI_P>
+static int bf16_same9_launch_n(Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp, const float* shift,
+                               const __bf16* r, __bf16* y) {
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
+    constexpr int LDS_BYTES = 3 * BM * 64 + 2 * NI_P * 1024 + 1024;
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static const hipError_t attr = hipFuncSetAttribute((const void*)conv_bf16_same9_kernel<TM, TN, WGM, WGN, NI_P>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (attr != hipSuccess) return ZSV_E_LAUNCH;
+    p.tiles_m = p.Mp / BM;
+    p.tiles_n = (p.P + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_bf16_same9_kernel<TM, TN, WGM, WGN, NI_P>), dim3(p.tiles_m * p.tiles_n), dim3(256), LDS_BYTES, stream,
+                       p, x, wp, shift, r, y);
+    return launch_status();
+}
+
+// one image for the nine (kh, kw) taps: kH = 3 with pH = 1 and a row short enough for the image to fit next to the A ring
+// (and at least four K chunks: with two -- the 64-channel forward of layer1 -- a tile has two images and starts with the bigger
+// one: measured 0.341 against 0.305 ms there)
+static bool bf16_same9_applicable(const zsv_conv_desc* d) {
+    const char* e = ZSV_KNOB(BF16_SAME9_MIN_CHUNKS);
+    const int min_chunks = e ? atoi(e) : 4;
+    return d->kH == 3 && d->pH == 1 && d->Wi <= 63 && (d->Cin + 31) / 32 >= min_chunks && ZSV_KNOB(BF16_NO_SAME9) == nullptr;
+}
+
+template <int TM>
+static int bf16_same9_launch(const zsv_conv_desc* d, Bf16Params& p, hipStream_t stream, const __bf16* x, const __bf16* wp,
+                             const float* shift, const __bf16* r, __bf16* y) {
+    return d->Wi <= 31 ? bf16_same9_launch_n<TM, 4, 1, 4, 20>(p, stream, x, wp, shift, r, y)
+                       : bf16_same9_launch_n<TM, 4, 1, 4, 24>(p, stream, x, wp, shift, r, y);
+}
+
 // stride 1, output extents = input extents, kW = 3 with pW = 1: taps are flattened shifts
 static bool bf16_same_applicable(const zsv_conv_desc* d) {
     return !bf16_folded(d) && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->kW == 3 && d->pW == 1 && d->To == d->Ti &&
@@ -963,6 +1166,8 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     // (the 64-row wave tiles of the small-P configuration have too few MFMAs per step to hide the
     // fragment masking of the shared-image kernel: measured slower there)
     if (bf16_same_applicable(d) && bm != 64 && !(bm == 128 && small)) {
+        if (bf16_same9_applicable(d))
+            return bm == 144 ? bf16_same9_launch<9>(d, p, s, xb, wp, shift, rb, yb) : bf16_same9_launch<8>(d, p, s, xb, wp, shift, rb, yb);
         if (bm == 144) return bf16_same_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
         return bf16_same_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     }
@@ -972,7 +1177,8 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     // SLOWER: 0.538 vs 0.458 ms on layer1's input gradient, step 21.4 vs 21.1 ms on one device; the 80 KB of LDS per workgroup and
     // the 33-piece image fill cost more than the bytes saved.  mfma_step keeps its 8-block form.)
     if (bf16_same_applicable(d) && bm == 64 && p.P >= 256 * 512 && ZSV_KNOB(BF16_NO_SAME64) == nullptr)
-        return bf16_same_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
+        return bf16_same9_applicable(d) ? bf16_same9_launch<4>(d, p, s, xb, wp, shift, rb, yb)
+                                        : bf16_same_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 144) return bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (small) return bf16_launch<4, 4, 2, 2>(p, s, xb, wp, shift, rb, yb);

@@ -12,6 +12,8 @@
     X(BF16_NO_SAME) \
     X(BF16_NO_TSAME) \
     X(BF16_NO_SAME64) \
+    X(BF16_NO_SAME9) \
+    X(BF16_SAME9_MIN_CHUNKS) \
     X(WINOT_NO_T32) \
     X(BF16_GROUP_OUTER) \
     X(BF16_NO_WGRAD) \
