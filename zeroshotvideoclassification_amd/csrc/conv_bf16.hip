@@ -1025,10 +1025,13 @@ static int bf16_same9_launch_n(Bf16Params& p, hipStream_t stream, const __bf16* 
 // one image for the nine (kh, kw) taps: kH = 3 with pH = 1 and a row short enough for the image to fit next to the A ring
 // (and at least four K chunks: with two -- the 64-channel forward of layer1 -- a tile has two images and starts with the bigger
 // one: measured 0.341 against 0.305 ms there)
-static bool bf16_same9_applicable(const zsv_conv_desc* d) {
+// and ONE row tile or 3x3x3 taps: with several row tiles of 1x3x3 taps (the 230 ... 576-channel forwards of the evaluation engine) the
+// 32-frame forward was 1 % slower with it (6.31 against 6.25 ms), C3D's 7 % faster (3.10 against 3.32 ms) -- measured, not modelled
+static bool bf16_same9_applicable(const zsv_conv_desc* d, int row_tiles) {
     const char* e = ZSV_KNOB(BF16_SAME9_MIN_CHUNKS);
     const int min_chunks = e ? atoi(e) : 4;
-    return d->kH == 3 && d->pH == 1 && d->Wi <= 63 && (d->Cin + 31) / 32 >= min_chunks && ZSV_KNOB(BF16_NO_SAME9) == nullptr;
+    return d->kH == 3 && d->pH == 1 && d->Wi <= 63 && (d->Cin + 31) / 32 >= min_chunks && (row_tiles == 1 || d->kT == 3) &&
+           ZSV_KNOB(BF16_NO_SAME9) == nullptr;
 }
 
 template <int TM>
@@ -1166,7 +1169,7 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     // (the 64-row wave tiles of the small-P configuration have too few MFMAs per step to hide the
     // fragment masking of the shared-image kernel: measured slower there)
     if (bf16_same_applicable(d) && bm != 64 && !(bm == 128 && small)) {
-        if (bf16_same9_applicable(d))
+        if (bf16_same9_applicable(d, p.Mp / bm))
             return bm == 144 ? bf16_same9_launch<9>(d, p, s, xb, wp, shift, rb, yb) : bf16_same9_launch<8>(d, p, s, xb, wp, shift, rb, yb);
         if (bm == 144) return bf16_same_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
         return bf16_same_launch<8, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
@@ -1177,7 +1180,7 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     // SLOWER: 0.538 vs 0.458 ms on layer1's input gradient, step 21.4 vs 21.1 ms on one device; the 80 KB of LDS per workgroup and
     // the 33-piece image fill cost more than the bytes saved.  mfma_step keeps its 8-block form.)
     if (bf16_same_applicable(d) && bm == 64 && p.P >= 256 * 512 && ZSV_KNOB(BF16_NO_SAME64) == nullptr)
-        return bf16_same9_applicable(d) ? bf16_same9_launch<4>(d, p, s, xb, wp, shift, rb, yb)
+        return bf16_same9_applicable(d, p.Mp / bm) ? bf16_same9_launch<4>(d, p, s, xb, wp, shift, rb, yb)
                                         : bf16_same_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 64) return bf16_launch<4, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
     if (bm == 144) return bf16_launch<9, 4, 1, 4>(p, s, xb, wp, shift, rb, yb);
