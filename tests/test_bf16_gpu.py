@@ -86,6 +86,44 @@ def test_conv_bf16_matches_fp64_of_rounded_operands(case):
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst ratio {(err / tol).max().item():.2f}"
 
 
+NINE_TAP_CASES = [
+    # n, cin, cout, (t,h,w), kernel: geometries that reach conv_bf16_same9_kernel (one LDS image for the nine (kh, kw) taps)
+    (3, 144, 64, (16, 56, 56), (1, 3, 3)),      # 64-row tile, W = 56 (24-piece image): the input gradient of layer1's spatial convolutions
+    (8, 128, 128, (16, 28, 28), (1, 3, 3)),     # one 128-row tile, W = 28 (20-piece image): layer2's input gradients
+    (2, 128, 144, (6, 20, 28), (3, 3, 3)),      # 3x3x3 taps (C3D / R3D-18), 144-row tile, ragged last voxel tile
+    (1, 160, 288, (4, 9, 7), (3, 3, 3)),        # 3x3x3, two row tiles, W = 7: a 256-voxel tile spans 36 image rows
+]
+
+
+@pytest.mark.parametrize("case", NINE_TAP_CASES, ids=[f"n{i}" for i in range(len(NINE_TAP_CASES))])
+def test_conv_bf16_nine_tap_image(case, monkeypatch):
+    """conv_bf16_same9_kernel against a CPU convolution of the same bf16-rounded operands (fp32 accumulation: these are too big
+    for an fp64 reference in seconds) and against the per-(kt, kh) image kernel it replaces (ZSV_BF16_NO_SAME9=1)."""
+    n, cin, cout, (t, h, w), k = case
+    p = (k[0] // 2, 1, 1)
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    x = bf16_round(torch.randn((n, cin, t, h, w), generator=g))
+    wgt = torch.randn((cout, cin) + k, generator=g) / np.sqrt(cin * np.prod(k))
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv3d(x, bf16_round(wgt), stride=1, padding=p) + shift.view(1, -1, 1, 1, 1)
+    d = ops.conv_desc(x.shape, wgt.shape, (1, 1, 1), p)
+    xb = to_ndhwc(x.to(DEV), inference.channel_pitch(cin))
+
+    def run():
+        blob = inference.pack_conv(d, wgt.to(DEV), None, shift.to(DEV))
+        return from_ndhwc(inference.conv_bf16(d, xb, blob, None, False), cout).cpu()
+
+    got = run()
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 2e-3
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst ratio {(err / tol).max().item():.2f}"
+    monkeypatch.setenv("ZSV_BF16_NO_SAME9", "1")
+    other = run()
+    # (with the chunk-outer walk -- three or more K chunks -- both kernels add the taps in the same order: identical bits are legitimate)
+    err = (got - other).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -7 + 2e-3).all()), f"nine-tap image vs per-(kt, kh) images: max diff {err.max().item():.3e}"
+
+
 @pytest.mark.parametrize("kernel,stride,padding", [((1, 7, 7), (1, 2, 2), (0, 3, 3)), ((3, 7, 7), (1, 2, 2), (1, 3, 3))])
 def test_clip_convolution_folded_form(kernel, stride, padding):
     """The stems (resnet.py:170,181): 3 channels, border materialised, kw folded into K."""
