@@ -602,9 +602,19 @@ def extra_eval_t32_bf16(dev, batches=6, repeats=5):
         res[name] = {"clips_per_s": round(r["n"] / statistics.median(passes), 1), "n": r["n"], "classes": ncls,
                      "passes_ms": [round(1e3 * p, 1) for p in passes]}
     rates = [v["clips_per_s"] for v in res.values()]
-    return {"workload": f"R(2+1)D-18 evaluate() protocol, {batches} batches x {CLIPS_PER_GPU} clips 3x32x{SIZE}x{SIZE}, bf16 engine "
-                        "(BatchNorm folded), cosine nearest class + 10 half-class splits (BASELINE.json configs[4], one GPU's share)",
-            "value": round(statistics.mean(rates), 1), "unit": "clips/s", "per_table": res}
+    out = {"workload": f"R(2+1)D-18 evaluate() protocol, {batches} batches x {CLIPS_PER_GPU} clips 3x32x{SIZE}x{SIZE}, bf16 engine "
+                       "(BatchNorm folded), cosine nearest class + 10 half-class splits (BASELINE.json configs[4], one GPU's share)",
+           "value": round(statistics.mean(rates), 1), "unit": "clips/s", "per_table": res}
+    # The protocol is host-inclusive (its accuracy bookkeeping runs on the host between the device passes): on a box whose host cores are
+    # shared with other jobs the passes of ONE table spread by 2-3x (round-4 record: 48 ... 163 ms where a quiet box reads 46.1 ... 46.8).
+    # Say so on the line rather than leave a low median unexplained; the fastest pass is what the device path sustains.
+    spread = max(max(v["passes_ms"]) / min(v["passes_ms"]) for v in res.values())
+    out["pass_spread"] = round(spread, 2)
+    if spread > 1.3:
+        best = [v["n"] / (1e-3 * min(v["passes_ms"])) for v in res.values()]
+        out["host_noise"] = True
+        out["value_fastest_passes"] = round(statistics.mean(best), 1)
+    return out
 
 
 def main():
