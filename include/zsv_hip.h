@@ -265,6 +265,14 @@ int zsv_conv3d_bf16_pack(const zsv_conv_desc* d, const float* w, const float* sc
 int zsv_conv3d_bf16_pack_dgrad(const zsv_conv_desc* d, const float* w_fwd, void* blob, void* stream);
 int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual,
                         int fuse_relu, void* y, void* stream);
+/* The same forward in front of a training-mode BatchNorm (no residual, no ReLU) with the BatchNorm's batch statistics taken in the
+ * epilogue: per column tile the per-channel sum and sum of squares of the values AS STORED (rounded to bf16: what a pass over y would
+ * read) go to bn_partials[row][0 / 1][Cp] (Cp = Cout rounded up to 32), `*rows` rows of them; zsv_conv3d_bf16_stat_rows(d) is an
+ * upper bound for the caller's allocation.  zsv_bn_cl_fwd_train_stats then skips its statistics pass (resnet.py:46-47,96-97 under
+ * main.py:172's autocast). */
+int32_t zsv_conv3d_bf16_stat_rows(const zsv_conv_desc* d);
+int zsv_conv3d_bf16_fwd_stats(const zsv_conv_desc* d, const void* x, const void* blob, void* y, float* bn_partials,
+                              int32_t rows_capacity, int32_t* rows, void* stream);
 /* (N, C<=4, T, H, W) fp32 clip -> [N][T][Hp][Wp][4] bf16, the frame placed at (padH, padW) inside a
  * zero border; Hp >= H + padH, Wp >= W + padW. */
 int zsv_clip_to_bf16(const float* x, int32_t N, int32_t C, int32_t T, int32_t H, int32_t W, int32_t padH,
@@ -293,6 +301,12 @@ size_t zsv_bn_cl_workspace_bytes(int64_t R, int32_t C);
 int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
                         float* save_mean, float* save_invstd, float* save_coef, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the batch statistics taken by the producing convolution's epilogue (zsv_conv3d_bf16_fwd_stats: `conv_rows` rows of
+ * [2][Cp] partial sums): the statistics pass over z is skipped. */
+int zsv_bn_cl_fwd_train_stats(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
+                              float* save_mean, float* save_invstd, float* save_coef, const float* conv_partials, int32_t conv_rows,
+                              void* workspace, size_t workspace_bytes, void* stream);
 int zsv_bn_cl_bwd(const void* dy, const void* y, const void* z, int64_t R, int32_t C, const float* gamma, const float* save_mean,
                   const float* save_invstd, const float* fwd_coef, int relu_mask, void* dz, void* g_out, float* dgamma, float* dbeta,
                   void* workspace, size_t workspace_bytes, void* stream);

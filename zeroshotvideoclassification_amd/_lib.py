@@ -87,6 +87,10 @@ SIGNATURES = {
     "zsv_meanpool_bf16": (c_int, [_P, c_int32, c_int32, c_int32, _P, _P]),
     "zsv_bn_cl_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "zsv_bn_cl_fwd_train": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "zsv_bn_cl_fwd_train_stats": (c_int, [_P, _P, c_int64, c_int32, _P, _P, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, c_int32, _P,
+                                          c_size_t, _P]),
+    "zsv_conv3d_bf16_stat_rows": (c_int32, [POINTER(ConvDesc)]),
+    "zsv_conv3d_bf16_fwd_stats": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int32, _P, _P]),
     "zsv_bn_cl_bwd": (c_int, [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "zsv_conv3d_bf16_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "zsv_conv3d_bf16_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_size_t, _P]),

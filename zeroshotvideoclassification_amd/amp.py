@@ -84,9 +84,29 @@ def _rows(t: torch.Tensor) -> int:
     return t.numel() // t.shape[-1]
 
 
-def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torch.Tensor], relu: bool, want_coef: bool = False):
+def conv_bf16_stats(d, x: torch.Tensor, blob: torch.Tensor):
+    """The training forward of a convolution in front of a BatchNorm: ``(z, partials, rows)`` with the BatchNorm's batch statistics
+    (per column tile: sum and sum of squares of the stored bf16 values, ``partials[:rows]`` of shape (rows, 2, Cp)) taken in the
+    convolution's epilogue (``zsv_conv3d_bf16_fwd_stats``).  ``bn_cl_fwd_train(..., conv_stats=(partials, rows))`` consumes them."""
+    import ctypes
+    lib = _lib.load()
+    cap = int(lib.zsv_conv3d_bf16_stat_rows(byref(d)))
+    if cap <= 0:
+        raise RuntimeError("zsv_conv3d_bf16_stat_rows: unsupported convolution geometry")
+    cp = channel_pitch(d.Cout)
+    z = torch.empty((d.N, d.To, d.Ho, d.Wo, cp), dtype=torch.bfloat16, device=x.device)
+    partials = torch.empty((cap, 2, cp), dtype=torch.float32, device=x.device)
+    rows = ctypes.c_int32(0)
+    _lib.check(lib.zsv_conv3d_bf16_fwd_stats(byref(d), x.data_ptr(), blob.data_ptr(), z.data_ptr(), partials.data_ptr(), cap,
+                                             ctypes.byref(rows), ops._stream()), "zsv_conv3d_bf16_fwd_stats")
+    return z, partials, int(rows.value)
+
+
+def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torch.Tensor], relu: bool, want_coef: bool = False,
+                    conv_stats=None):
     """Train-mode ``BatchNorm3d`` (+ residual) (+ ReLU) on a channels-last bf16 tensor.  Returns (y, mean, invstd), or
-    (y, mean, invstd, coef) with ``want_coef``: the (2, Cp) scale / shift rows the backward recomputes the ReLU mask from."""
+    (y, mean, invstd, coef) with ``want_coef``: the (2, Cp) scale / shift rows the backward recomputes the ReLU mask from.
+    ``conv_stats`` = (partials, rows) of ``conv_bf16_stats``: the statistics pass over z is skipped."""
     lib = _lib.load()
     c = bn.num_features
     r = _rows(z)
@@ -102,11 +122,20 @@ def bn_cl_fwd_train(z: torch.Tensor, bn: nn.BatchNorm3d, residual: Optional[torc
     if bn.momentum is None and track:
         raise NotImplementedError("amp: BatchNorm3d(momentum=None) (cumulative moving average) is not used by the reference")
     momentum = 0.0 if bn.momentum is None else float(bn.momentum)
-    _lib.check(lib.zsv_bn_cl_fwd_train(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
-                                       bn.running_mean.data_ptr() if track else None,
-                                       bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
-                                       1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ops._ptr(coef), ws.data_ptr(),
-                                       nbytes, ops._stream()), "zsv_bn_cl_fwd_train")
+    if conv_stats is not None:
+        partials, rows = conv_stats
+        _lib.check(lib.zsv_bn_cl_fwd_train_stats(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
+                                                 bn.running_mean.data_ptr() if track else None,
+                                                 bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
+                                                 1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ops._ptr(coef),
+                                                 partials.data_ptr(), rows, ws.data_ptr(), nbytes, ops._stream()),
+                   "zsv_bn_cl_fwd_train_stats")
+    else:
+        _lib.check(lib.zsv_bn_cl_fwd_train(z.data_ptr(), ops._ptr(residual), r, c, ops._ptr(bn.weight), ops._ptr(bn.bias),
+                                           bn.running_mean.data_ptr() if track else None,
+                                           bn.running_var.data_ptr() if track else None, momentum, float(bn.eps),
+                                           1 if relu else 0, y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ops._ptr(coef), ws.data_ptr(),
+                                           nbytes, ops._stream()), "zsv_bn_cl_fwd_train")
     if track:
         pending = getattr(_state, "nbt_pending", None)
         if pending is not None:
@@ -270,12 +299,18 @@ class Bf16TrainPath:
         blob = pack_conv(d, u.conv.weight.detach(), None, None)
         timer = None if torch.cuda.is_current_stream_capturing() else ops.KERNEL_TIMER      # (timing events cannot be captured)
         mark = timer.start() if timer is not None and timer.wants("conv_bf16_fwd", d) else None
-        z = conv_bf16(d, x, blob, None, False)
+        # the BatchNorm's batch statistics come out of the convolution's epilogue (ZSV_AMP_NO_CONV_STATS=1: a pass over z instead)
+        stats = None
+        if os.environ.get("ZSV_AMP_NO_CONV_STATS"):
+            z = conv_bf16(d, x, blob, None, False)
+        else:
+            z, partials, rows = conv_bf16_stats(d, x, blob)
+            stats = (partials, rows)
         if mark is not None:
             timer.stop(mark)
         # (a unit with ReLU and no residual keeps its scale / shift rows: the backward recomputes the mask from z, y is not read there)
         keep_coef = tape is not None and u.relu and residual is None
-        out = bn_cl_fwd_train(z, u.bn, residual, u.relu, want_coef=keep_coef)
+        out = bn_cl_fwd_train(z, u.bn, residual, u.relu, want_coef=keep_coef, conv_stats=stats)
         y, mean, invstd = out[0], out[1], out[2]
         if tape is not None:
             r = _Record()

@@ -52,6 +52,7 @@ struct Bf16Params {
     int tiles_m, tiles_n;
     int relu;
     int cc_outer;              // shared-image kernel: walk the K chunks outermost (image rows of one chunk stay in L2 across the kh groups)
+    float* stat;               // != nullptr: per column tile the sums and sums of squares of the STORED (bf16-rounded) values, [tiles_n][2][CoutP]
 };
 
 // 16-byte slot swizzle of a 64-byte LDS row: ds_read_b128 serves lanes in the groups
@@ -142,11 +143,22 @@ __device__ __forceinline__ void mfma_step(f32x4 (&acc)[TM][TN], unsigned sa, uns
 // `sh` = this row tile's shifts in LDS.
 // Column c of the tile is voxel n0 + c, or -- hb_shift > 0, the (frames x positions) tiles of
 // conv_bf16_tsame_kernel -- voxel n0 + (c >> hb_shift) * frame_stride + (c & (HB - 1)).
+// prm.stat != nullptr (training forward in front of a BatchNorm: no residual, no ReLU): the tile's per-channel sum and sum of squares of
+// the values as STORED (rounded to bf16 -- what the BatchNorm's own statistics pass would read back) go to
+// stat[tn][0 / 1][m0 + channel]: in-lane over the wave's column blocks, 16-lane DPP sums over a block's columns, the waves of a row
+// through `scratch` (the stage area of LDS, free after the K loop) in wave order -- fixed order, reproducible.
 template <int TM, int TN, int BM, int BN>
 __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM][TN], const float* sh,
                                          const __bf16* __restrict__ R, __bf16* __restrict__ Y, int m0, int n0, int tm,
-                                         int wm, int wn, int tid, int hb_shift = 0, int frame_stride = 0) {
+                                         int wm, int wn, int tid, int hb_shift = 0, int frame_stride = 0, float* scratch = nullptr,
+                                         int tn = 0, int wgn = 4) {
     const int lane = tid & 63;
+    const bool stats = prm.stat != nullptr;
+    float ssum[TM][4], ssq[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ssum[i][e] = ssq[i][e] = 0.f;
     auto voxel = [&](int c) { return hb_shift ? n0 + (c >> hb_shift) * frame_stride + (c & ((1 << hb_shift) - 1)) : n0 + c; };
     const float floor_ = prm.relu ? 0.f : -__builtin_inff();
     const int g = lane >> 4;
@@ -185,6 +197,14 @@ __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM]
                     o[4 + e] = (__bf16)fmaxf(hi[e], floor_);
                 }
                 if (cv && m0 + ch < prm.CoutP) *(bf16x8*)(Y + row_off + ch) = o;
+                if (stats && cv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = (float)o[e], b = (float)o[4 + e];
+                        ssum[2 * k][e] += a; ssq[2 * k][e] = fmaf(a, a, ssq[2 * k][e]);
+                        ssum[2 * k + 1][e] += b; ssq[2 * k + 1][e] = fmaf(b, b, ssq[2 * k + 1][e]);
+                    }
+                }
             }
             if (TM & 1) {                             // unpaired last row block: 4 channels per lane
                 const int ch = ch_t + 16 * (TM - 1) + 4 * g;
@@ -199,11 +219,50 @@ __device__ __forceinline__ void epilogue(const Bf16Params& prm, f32x4 (&acc)[TM]
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(v[e], floor_);
                 if (cv && m0 + ch < prm.CoutP) *(bf16x4*)(Y + row_off + ch) = o;
+                if (stats && cv) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = (float)o[e];
+                        ssum[TM - 1][e] += a; ssq[TM - 1][e] = fmaf(a, a, ssq[TM - 1][e]);
+                    }
+                }
             }
         }
     };
     if (R != nullptr) finish(std::true_type{});
     else finish(std::false_type{});
+    if (stats) {
+        // tile-relative channel of (row block i, element e) of this lane: the paired blocks interleave (tile_channel)
+        auto row16 = [](float v) {                   // sum over the 16 lanes of a DPP row (they hold the block's 16 columns)
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+            return v;
+        };
+        __syncthreads();                              // every wave is past its last fragment read: the stage area is free
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bool paired = i < 2 * NPAIR;
+            const int chb = paired ? ch_t + 32 * (i >> 1) + 8 * g + 4 * (i & 1) : ch_t + 16 * (TM - 1) + 4 * g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = row16(ssum[i][e]), b = row16(ssq[i][e]);
+                if ((lane & 15) == 0) {
+                    scratch[(wn * BM + chb + e) * 2] = a;
+                    scratch[(wn * BM + chb + e) * 2 + 1] = b;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BM && m0 + tid < prm.CoutP) {
+            float a = 0.f, b = 0.f;
+            for (int w = 0; w < wgn; ++w) { a += scratch[(w * BM + tid) * 2]; b += scratch[(w * BM + tid) * 2 + 1]; }
+            float* out = prm.stat + (size_t)tn * 2 * prm.CoutP + m0 + tid;
+            out[0] = a;
+            out[prm.CoutP] = b;
+        }
+    }
     // channels between the last packed row and the pitch (e.g. 144 -> 160) stay zero
     const int covered = prm.tiles_m * BM;
     if (tm == prm.tiles_m - 1 && covered < prm.CoutP) {
@@ -347,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Params prm, const
         nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
 
-    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid, 0, 0, (float*)lds, tn, WGN);
 #endif
 }
 
@@ -525,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same_kernel(Bf16Params prm, 
             if (img % prm.nchunk != prm.nchunk - 1) tap -= KW;  // same (kt,kh) group, next chunk
         }
     }
-    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid, 0, 0, (float*)lds, tn, WGN);
 #endif
 }
 
@@ -696,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_same9_kernel(Bf16Params prm,
             if (++kt == prm.kT) { kt = 0; ++cc; }
         } else if (++cc == prm.nchunk) { cc = 0; ++kt; }
     }
-    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid);
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, wm, wn, tid, 0, 0, (float*)lds, tn, WGN);
 #endif
 }
 
@@ -830,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_tsame_kernel(Bf16Params prm,
             abuf2 = abuf2 == 2 ? 0 : abuf2 + 1;
         }
     }
-    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, 0, wave, tid, HB_SHIFT, HW);
+    epilogue<TM, TN, BM, BN>(prm, acc, (const float*)(lds + SHIFT_AT), R, Y, m0, n0, tm, 0, wave, tid, HB_SHIFT, HW, (float*)lds, tn, 4);
 #endif
 }
 
@@ -1124,8 +1183,29 @@ int zsv_conv3d_bf16_pack_dgrad(const zsv_conv_desc* d, const float* w_fwd, void*
     return launch_status();
 }
 
+static int bf16_fwd_impl(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual, int fuse_relu, void* y,
+                         float* stat, int32_t stat_rows_capacity, int32_t* stat_rows, void* stream);
+
 int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual, int fuse_relu,
                         void* y, void* stream) {
+    return bf16_fwd_impl(d, x, blob, residual, fuse_relu, y, nullptr, 0, nullptr, stream);
+}
+
+// rows of the statistics array a forward of this geometry may write (an upper bound: the smallest column tile is 128 voxels)
+int32_t zsv_conv3d_bf16_stat_rows(const zsv_conv_desc* d) {
+    if (d == nullptr || bf16_check(d) != ZSV_OK) return 0;
+    const long P = (long)d->N * d->To * d->Ho * d->Wo;
+    return (int32_t)((P + 127) / 128);
+}
+
+int zsv_conv3d_bf16_fwd_stats(const zsv_conv_desc* d, const void* x, const void* blob, void* y, float* bn_partials,
+                              int32_t rows_capacity, int32_t* rows, void* stream) {
+    if (bn_partials == nullptr || rows == nullptr) return ZSV_E_NULL;
+    return bf16_fwd_impl(d, x, blob, nullptr, 0, y, bn_partials, rows_capacity, rows, stream);
+}
+
+static int bf16_fwd_impl(const zsv_conv_desc* d, const void* x, const void* blob, const void* residual, int fuse_relu, void* y,
+                         float* stat, int32_t stat_rows_capacity, int32_t* stat_rows, void* stream) {
     if (d == nullptr) return ZSV_E_NULL;
     const int st = bf16_check(d);
     if (st != ZSV_OK) return st;
@@ -1148,6 +1228,12 @@ int zsv_conv3d_bf16_fwd(const zsv_conv_desc* d, const void* x, const void* blob,
     p.pT = d->pT; p.pH = d->pH; p.pW = d->pW;
     p.P = d->N * p.ToHoWo;
     p.relu = fuse_relu ? 1 : 0;
+    p.stat = stat;
+    if (stat != nullptr) {
+        // one row per column tile of the kernel chosen below (256 voxels, 128 in the small-problem form)
+        if (residual != nullptr || fuse_relu || stat_rows_capacity < zsv_conv3d_bf16_stat_rows(d)) return ZSV_E_WORKSPACE;
+        *stat_rows = (int32_t)(((long)(p.Mp / 128) * ((p.P + 255) / 256) < 384 && bm == 128) ? (p.P + 127) / 128 : (p.P + 255) / 256);
+    }
     // (with >= 3 chunks of 32 input channels the image rows of all chunks of a (kt,kh) group no longer fit the XCD's L2 next to the
     // other workgroups': 1.19 GB fetched for 353 MB of dz on layer1's input gradient, profiles/r04_bf16_training_kernels_pmc.json)
     p.cc_outer = (p.nchunk >= 3 && ZSV_KNOB(BF16_GROUP_OUTER) == nullptr) ? 1 : 0;

@@ -436,9 +436,31 @@ size_t zsv_bn_cl_workspace_bytes(int64_t R, int32_t C) {
     return cl_workspace_bytes(sh, nb);
 }
 
+static int bn_cl_fwd_train_impl(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
+                                float* save_mean, float* save_invstd, float* save_coef, const float* conv_partials, int32_t conv_rows,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
                         float* save_mean, float* save_invstd, float* save_coef, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_cl_fwd_train_impl(z, residual, R, C, gamma, beta, running_mean, running_var, momentum, eps, fuse_relu, y, save_mean,
+                                save_invstd, save_coef, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+int zsv_bn_cl_fwd_train_stats(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
+                              float* save_mean, float* save_invstd, float* save_coef, const float* conv_partials, int32_t conv_rows,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    if (conv_partials == nullptr || conv_rows <= 0) return ZSV_E_NULL;
+    return bn_cl_fwd_train_impl(z, residual, R, C, gamma, beta, running_mean, running_var, momentum, eps, fuse_relu, y, save_mean,
+                                save_invstd, save_coef, conv_partials, conv_rows, workspace, workspace_bytes, stream);
+}
+
+static int bn_cl_fwd_train_impl(const void* z, const void* residual, int64_t R, int32_t C, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int fuse_relu, void* y,
+                                float* save_mean, float* save_invstd, float* save_coef, const float* conv_partials, int32_t conv_rows,
+                                void* workspace, size_t workspace_bytes, void* stream) {
     ClShape sh;
     int nb = 0;
     const int st = cl_shape(R, C, &sh, &nb);
@@ -449,9 +471,14 @@ int zsv_bn_cl_fwd_train(const void* z, const void* residual, int64_t R, int32_t 
     float* partial = (float*)workspace;
     float* coef = save_coef ? save_coef : partial + (size_t)nb * 2 * sh.Cp;       // [2][Cp]: kept by the caller for the backward's mask
     const size_t lds = (size_t)sh.RL * 2 * sh.Cp * sizeof(float);
-    hipLaunchKernelGGL((bn_cl_reduce_kernel<0>), dim3(nb), dim3(256), lds, s, sh, (const u32x4v*)z, nullptr, nullptr, nullptr, partial);
-    hipLaunchKernelGGL(bn_cl_fwd_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, partial, nb, C, sh.Cp, (long)R, gamma, beta,
-                       running_mean, running_var, momentum, eps, save_mean, save_invstd, coef);
+    if (conv_partials != nullptr) {      // the producing convolution's epilogue took the sums (zsv_conv3d_bf16_fwd_stats): same layout
+        hipLaunchKernelGGL(bn_cl_fwd_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, conv_partials, (int)conv_rows, C, sh.Cp,
+                           (long)R, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, coef);
+    } else {
+        hipLaunchKernelGGL((bn_cl_reduce_kernel<0>), dim3(nb), dim3(256), lds, s, sh, (const u32x4v*)z, nullptr, nullptr, nullptr, partial);
+        hipLaunchKernelGGL(bn_cl_fwd_finalize_kernel, dim3((sh.Cp + 15) / 16), dim3(256), 0, s, partial, nb, C, sh.Cp, (long)R, gamma, beta,
+                           running_mean, running_var, momentum, eps, save_mean, save_invstd, coef);
+    }
     const u32x4v* zz = (const u32x4v*)z;
     const u32x4v* rr = (const u32x4v*)residual;
     u32x4v* yy = (u32x4v*)y;
