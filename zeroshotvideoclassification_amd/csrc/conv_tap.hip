@@ -418,7 +418,27 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void conv_tap_dma_kernel(IgemmPa
 // C = sum_s slab[s] (+ bias[m]) (ReLU): fixed order, deterministic
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int ksplit, long elems, int M,
                                                             int oS, const float* __restrict__ bias, int relu,
-                                                            float* __restrict__ C) {
+                                                            float* __restrict__ C, bool vec4) {
+    if (vec4) {
+        // four consecutive voxels per thread (oS % 4 == 0: they share their channel) and the loads of four parts issued before their
+        // adds -- per element the same order of addition as the scalar loop, the same bits
+        const long quads = elems >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + i;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 3 < ksplit; s += 4) {
+                const f32x4 a = src[(size_t)s * quads], b = src[(size_t)(s + 1) * quads], c = src[(size_t)(s + 2) * quads],
+                            d = src[(size_t)(s + 3) * quads];
+                v += a; v += b; v += c; v += d;
+            }
+            for (; s < ksplit; ++s) v += src[(size_t)s * quads];
+            if (bias) { const float bv = bias[((4 * i) / oS) % M]; v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv; }
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            reinterpret_cast<f32x4*>(C)[i] = v;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < elems; i += (long)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < ksplit; ++s) v += slabs[(size_t)s * elems + i];
@@ -430,10 +450,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 int splitk_reduce(const float* slabs, int ksplit, long elems, int M, int oS, const float* bias, int relu, float* C,
                   hipStream_t stream) {
-    long blocks = (elems + 255) / 256;
+    const bool vec4 = oS % 4 == 0 && elems % 4 == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(C)) & 15) == 0 &&
+                      ZSV_KNOB(SPLITK_REDUCE_SCALAR) == nullptr;
+    long blocks = ((vec4 ? elems / 4 : elems) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slabs, ksplit, elems, M, oS, bias,
-                       relu, C);
+                       relu, C, vec4);
     return hipGetLastError() == hipSuccess ? ZSV_OK : ZSV_E_LAUNCH;
 }
 

@@ -324,7 +324,13 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
         float s = 0.f;
         if (live) {
             const float* src = slabs + j;
-            for (int k = g; k < slices; k += 8) s += src[(size_t)k * slab];
+            int k = g;
+            for (; k + 24 < slices; k += 32) {                    // four loads in flight, added in the same order
+                const float v0 = src[(size_t)k * slab], v1 = src[(size_t)(k + 8) * slab];
+                const float v2 = src[(size_t)(k + 16) * slab], v3 = src[(size_t)(k + 24) * slab];
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; k < slices; k += 8) s += src[(size_t)k * slab];
         }
         part[g][e] = s;
         __syncthreads();
@@ -354,7 +360,14 @@ __global__ __launch_bounds__(256) void slab_sum_rows_kernel(const float* __restr
     const float* src = slabs + (size_t)co * len;
     for (int i = 4 * (int)threadIdx.x; i < len; i += 1024) {
         f32x4 t = *reinterpret_cast<const f32x4*>(src + i);
-        for (int k = 1; k < slices; ++k) t += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab + i);
+        int k = 1;
+        for (; k + 2 < slices; k += 3) {                          // three slices' loads in flight, added in the same order
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)k * slab + i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * slab + i);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 2) * slab + i);
+            t += v0; t += v1; t += v2;
+        }
+        for (; k < slices; ++k) t += *reinterpret_cast<const f32x4*>(src + (size_t)k * slab + i);
         *reinterpret_cast<f32x4*>(row + i) = t;
     }
     __syncthreads();

@@ -447,10 +447,23 @@ __global__ __launch_bounds__(256) void wgrad_wino_sum_kernel(const float* __rest
         float s[PTS];
 #pragma unroll
         for (int p = 0; p < PTS; ++p) s[p] = 0.f;
-        if (live)
-            for (int k = grp; k < slices; k += 8)
+        if (live) {
+            int k = grp;
+            for (; k + 8 < slices; k += 16) {                     // two slices' loads in flight, added in the same order
+                float v[2][PTS];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int p = 0; p < PTS; ++p) v[u][p] = slabs[((size_t)(k + 8 * u) * PTS + p) * plane + j];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int p = 0; p < PTS; ++p) s[p] += v[u][p];
+            }
+            for (; k < slices; k += 8)
 #pragma unroll
                 for (int p = 0; p < PTS; ++p) s[p] += slabs[((size_t)k * PTS + p) * plane + j];
+        }
 #pragma unroll
         for (int p = 0; p < PTS; ++p) part[grp][p][e] = s[p];
         __syncthreads();

@@ -63,6 +63,7 @@
     X(WINOT_NO_F43) \
     X(WINO_NO_X4) \
     X(NO_SLAB_SUM_ROWS) \
+    X(SPLITK_REDUCE_SCALAR) \
     X(NO_PACK_TILED) \
     X(NO_T2_DENSE) \
     X(WINO_NO_VW) \
