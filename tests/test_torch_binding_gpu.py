@@ -93,3 +93,26 @@ def test_errors_name_the_status():
         ns.conv3d_fwd(torch.zeros(1, 3, 2, 4, 4, device=DEV), torch.zeros(4, 5, 1, 3, 3, device=DEV), None, [1, 1, 1], [0, 1, 1], False)
     with pytest.raises(RuntimeError, match="contiguous"):
         ns.conv3d_fwd(torch.zeros(1, 3, 2, 4, 8, device=DEV)[..., ::2], torch.zeros(4, 3, 1, 3, 3, device=DEV), None, [1, 1, 1], [0, 1, 1], False)
+
+
+def test_relu_and_linear_operators():
+    """`torch.ops.zsv.relu` / `linear` (network.MLP, network.py:603-617) against torch CPU fp64 and the ctypes binding."""
+    ns = torch_ops.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(22, 512, generator=g)
+    w = torch.randn(300, 512, generator=g) / 512 ** 0.5
+    b = torch.randn(300, generator=g)
+    gy = torch.randn(22, 300, generator=g)
+    xr, wr, br = (v.double().requires_grad_() for v in (x, w, b))
+    yr = torch.relu(torch.nn.functional.linear(xr, wr, br))
+    yr.backward(gy.double())
+    xd, wd, bd = (v.to(DEV).requires_grad_() for v in (x, w, b))
+    y = ns.relu(ns.linear(xd, wd, bd))
+    y.backward(gy.to(DEV))
+    close(y, yr.detach(), what="relu(linear) forward")
+    close(xd.grad, xr.grad, what="linear input gradient")
+    close(wd.grad, wr.grad, what="linear weight gradient")
+    close(bd.grad, br.grad, what="linear bias gradient")
+    xc, wc, bc = (v.to(DEV).requires_grad_() for v in (x, w, b))
+    yc = ops.linear(xc, wc, bc, relu=True)
+    assert torch.equal(ns.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True), yc.detach()), "fused linear + relu differs between the bindings"

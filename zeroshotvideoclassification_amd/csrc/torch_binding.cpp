@@ -4,7 +4,7 @@
 // Host C++ only (built with g++ against the torch headers; no device code, nothing generated): every operator builds the POD
 // descriptor from the tensor sizes, takes the stream torch is currently recording on, allocates the workspace from torch's caching
 // allocator and calls the same `zsv_*` entry point the ctypes glue (`_lib.py` / `ops.py`) calls.  The differentiable forms
-// (`zsv::conv3d`, `zsv::batch_norm_relu`) register an Autograd kernel, so C++ / TorchScript callers get the reference's
+// (`zsv::conv3d`, `zsv::batch_norm_relu`, `zsv::relu`, `zsv::linear`) register an Autograd kernel, so C++ / TorchScript callers get the reference's
 // `nn.Conv3d` (resnet.py:23-30,40-52; network.py:102-117) and `nn.BatchNorm3d (+ ReLU)` (resnet.py:46-49,94-98) semantics
 // without Python.  The training harness of this repo keeps the ctypes path (panel cache, side-stream weight gradients, fused
 // block tails live in ops.py); tests/test_torch_binding_gpu.py checks both bindings against each other bit for bit.
@@ -143,6 +143,69 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> bn_train_bwd(const at::Tensor& dy
     return {dx, dgamma, dbeta};
 }
 
+// nn.ReLU (resnet.py:49; network.py:147-166,614) and its backward (mask from the saved output, like ReLU(inplace=True))
+at::Tensor relu_fwd(const at::Tensor& x) {
+    TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(), "relu: contiguous float32 GPU tensor expected");
+    at::Tensor y = at::empty_like(x);
+    ok(zsv_relu_fwd(x.data_ptr<float>(), y.data_ptr<float>(), x.numel(), stream_of(x)), "zsv_relu_fwd");
+    return y;
+}
+
+at::Tensor relu_bwd(const at::Tensor& dy, const at::Tensor& y) {
+    TORCH_CHECK(dy.is_cuda() && y.is_cuda() && dy.scalar_type() == at::kFloat && y.scalar_type() == at::kFloat && dy.is_contiguous() &&
+                    y.is_contiguous() && dy.numel() == y.numel(), "relu_bwd: two contiguous float32 GPU tensors of one size expected");
+    at::Tensor dx = at::empty_like(dy);
+    ok(zsv_relu_bwd(dy.data_ptr<float>(), y.data_ptr<float>(), dx.data_ptr<float>(), dy.numel(), stream_of(dy)), "zsv_relu_bwd");
+    return dx;
+}
+
+// nn.Linear (+ ReLU) of network.MLP (network.py:603-617): y = relu?(x w^T + b), x (rows, in), w (out, in)
+at::Tensor linear_fwd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, bool relu) {
+    want(x, "x", 2);
+    want(w, "w", 2);
+    TORCH_CHECK(x.size(1) == w.size(1), "linear: x has ", x.size(1), " features, w expects ", w.size(1));
+    const int32_t rows = (int32_t)x.size(0), in = (int32_t)x.size(1), out = (int32_t)w.size(0);
+    const float* b = nullptr;
+    if (bias.has_value() && bias->defined()) {
+        want(*bias, "bias", 1);
+        TORCH_CHECK(bias->numel() == out, "linear: bias has ", bias->numel(), " entries for ", out, " outputs");
+        b = bias->data_ptr<float>();
+    }
+    at::Tensor y = at::empty({rows, out}, x.options());
+    const size_t bytes = zsv_linear_fwd_workspace_bytes(rows, in, out);
+    at::Tensor ws = scratch(bytes, x);
+    ok(zsv_linear_fwd(x.data_ptr<float>(), w.data_ptr<float>(), b, y.data_ptr<float>(), rows, in, out, relu ? 1 : 0, ws.data_ptr(), bytes,
+                      stream_of(x)),
+       "zsv_linear_fwd");
+    return y;
+}
+
+at::Tensor linear_dgrad(const at::Tensor& dy, const at::Tensor& w) {
+    want(dy, "dy", 2);
+    want(w, "w", 2);
+    TORCH_CHECK(dy.size(1) == w.size(0), "linear_dgrad: dy has ", dy.size(1), " columns, w has ", w.size(0), " rows");
+    const int32_t rows = (int32_t)dy.size(0), in = (int32_t)w.size(1), out = (int32_t)w.size(0);
+    at::Tensor dx = at::empty({rows, in}, dy.options());
+    const size_t bytes = zsv_linear_dgrad_workspace_bytes(rows, in, out);
+    at::Tensor ws = scratch(bytes, dy);
+    ok(zsv_linear_dgrad(dy.data_ptr<float>(), w.data_ptr<float>(), dx.data_ptr<float>(), rows, in, out, ws.data_ptr(), bytes, stream_of(dy)),
+       "zsv_linear_dgrad");
+    return dx;
+}
+
+at::Tensor linear_wgrad(const at::Tensor& x, const at::Tensor& dy) {
+    want(x, "x", 2);
+    want(dy, "dy", 2);
+    TORCH_CHECK(x.size(0) == dy.size(0), "linear_wgrad: x and dy must have the same number of rows");
+    const int32_t rows = (int32_t)x.size(0), in = (int32_t)x.size(1), out = (int32_t)dy.size(1);
+    at::Tensor dw = at::empty({out, in}, x.options());
+    const size_t bytes = zsv_linear_wgrad_workspace_bytes(rows, in, out);
+    at::Tensor ws = scratch(bytes, x);
+    ok(zsv_linear_wgrad(x.data_ptr<float>(), dy.data_ptr<float>(), dw.data_ptr<float>(), rows, in, out, ws.data_ptr(), bytes, stream_of(x)),
+       "zsv_linear_wgrad");
+    return dw;
+}
+
 std::string version() { return zsv_version(); }
 
 // ---- differentiable forms ---------------------------------------------------------------------------------------------------
@@ -195,6 +258,44 @@ at::Tensor batch_norm_relu_autograd(const at::Tensor& x, const at::Tensor& gamma
     return BatchNormReluFn::apply(x, gamma, beta, running_mean, running_var, momentum, eps, relu);
 }
 
+struct ReluFn : public torch::autograd::Function<ReluFn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        at::Tensor y = relu_fwd(x.contiguous());
+        ctx->save_for_backward({y});
+        return y;
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        return {relu_bwd(grads[0].contiguous(), ctx->get_saved_variables()[0])};
+    }
+};
+at::Tensor relu_autograd(const at::Tensor& x) { return ReluFn::apply(x); }
+
+struct LinearFn : public torch::autograd::Function<LinearFn> {
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w,
+                              const c10::optional<at::Tensor>& bias) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        ctx->save_for_backward({x, w});
+        ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
+        return linear_fwd(x, w, bias, false);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor dy = grads[0].contiguous();
+        at::Tensor dx, dw, db;
+        if (ctx->needs_input_grad(0)) dx = linear_dgrad(dy, saved[1]);
+        if (ctx->needs_input_grad(1)) dw = linear_wgrad(saved[0], dy);
+        if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) db = dy.sum(0);
+        return {dx, dw, db};
+    }
+};
+at::Tensor linear_autograd(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias) {
+    return LinearFn::apply(x, w, bias);
+}
+at::Tensor linear_plain(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias) {
+    return linear_fwd(x, w, bias, false);
+}
+
 // without autograd in the key set (inference mode): the forward alone
 at::Tensor conv3d_plain(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, at::IntArrayRef stride,
                         at::IntArrayRef padding) {
@@ -217,6 +318,13 @@ TORCH_LIBRARY(zsv, m) {
           "float eps, bool relu=False) -> (Tensor, Tensor, Tensor)");
     m.def("bn_train_bwd(Tensor dy, Tensor x, Tensor y, Tensor weight, Tensor bias, Tensor save_mean, Tensor save_invstd, "
           "bool relu=False) -> (Tensor, Tensor, Tensor)");
+    m.def("relu_fwd(Tensor x) -> Tensor");
+    m.def("relu_bwd(Tensor dy, Tensor y) -> Tensor");
+    m.def("linear_fwd(Tensor x, Tensor w, Tensor? bias, bool relu=False) -> Tensor");
+    m.def("linear_dgrad(Tensor dy, Tensor w) -> Tensor");
+    m.def("linear_wgrad(Tensor x, Tensor dy) -> Tensor");
+    m.def("relu(Tensor x) -> Tensor");
+    m.def("linear(Tensor x, Tensor w, Tensor? bias) -> Tensor");
     m.def("conv3d(Tensor x, Tensor w, Tensor? bias, int[3] stride, int[3] padding) -> Tensor");
     m.def("batch_norm_relu(Tensor x, Tensor weight, Tensor bias, Tensor(a!) running_mean, Tensor(b!) running_var, float momentum, "
           "float eps, bool relu=False) -> Tensor");
@@ -230,9 +338,18 @@ TORCH_LIBRARY_IMPL(zsv, CUDA, m) {      // torch's name of the HIP backend on RO
     m.impl("bn_train_bwd", bn_train_bwd);
     m.impl("conv3d", conv3d_plain);
     m.impl("batch_norm_relu", batch_norm_relu_plain);
+    m.impl("relu_fwd", relu_fwd);
+    m.impl("relu_bwd", relu_bwd);
+    m.impl("linear_fwd", linear_fwd);
+    m.impl("linear_dgrad", linear_dgrad);
+    m.impl("linear_wgrad", linear_wgrad);
+    m.impl("relu", relu_fwd);
+    m.impl("linear", linear_plain);
 }
 
 TORCH_LIBRARY_IMPL(zsv, Autograd, m) {
     m.impl("conv3d", conv3d_autograd);
     m.impl("batch_norm_relu", batch_norm_relu_autograd);
+    m.impl("relu", relu_autograd);
+    m.impl("linear", linear_autograd);
 }

@@ -17,7 +17,8 @@ import os
 import torch
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzsv_torch.so")
-OPERATORS = ("version", "conv3d_fwd", "conv3d_dgrad", "conv3d_wgrad", "bn_train_fwd", "bn_train_bwd", "conv3d", "batch_norm_relu")
+OPERATORS = ("version", "conv3d_fwd", "conv3d_dgrad", "conv3d_wgrad", "bn_train_fwd", "bn_train_bwd", "relu_fwd", "relu_bwd",
+             "linear_fwd", "linear_dgrad", "linear_wgrad", "conv3d", "batch_norm_relu", "relu", "linear")
 _loaded = False
 
 
